@@ -1,0 +1,185 @@
+/*
+ * cfs_hip.h -- C ABI of libcfs_hip.so: the MI355X (gfx950) Convex-Feasible-Set inner loop.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (JessicaLeu-code/MotionPlanning_5D_m) is MATLAB with no FFI of its own; the entry points
+ * below are what a MEX gateway for that path binds (see INTEGRATION.md and matlab/cfs_mex.cpp).
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *   - all floating point is IEEE fp64; all matrices are COLUMN-MAJOR exactly as MATLAB hands
+ *     them (mxGetPr); a leading batch dimension B, where present, is the slowest one;
+ *   - plain pointers and sizes only; the caller owns every buffer; the library owns only the
+ *     opaque cfs_problem handle (device copies of the problem-family constants and workspace);
+ *   - functions return CFS_SUCCESS (0) or a negative cfs_error; they never abort; the text of
+ *     the last error of the calling thread is available from cfs_last_error();
+ *   - entry points with the suffix _device take DEVICE pointers and a hipStream_t (passed as
+ *     void*); they enqueue work and return without synchronising; the others take HOST
+ *     pointers, copy in/out and synchronise;
+ *   - there is no CPU fallback anywhere: without a HIP device every compute entry point
+ *     returns CFS_ERR_NO_DEVICE.
+ */
+#ifndef CFS_HIP_H
+#define CFS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFS_ABI_VERSION 1
+#define CFS_MAX_LINKS 8   /* rows of robot.DH / entries of robot.cap the library accepts */
+#define CFS_MAX_OBS 32    /* obstacles per problem                                       */
+#define CFS_MAX_H 64      /* horizon (waypoints), one wavefront lane per waypoint         */
+
+/* error codes (return values) */
+typedef enum cfs_error {
+    CFS_SUCCESS = 0,
+    CFS_ERR_INVALID_ARG = -1,
+    CFS_ERR_NO_DEVICE = -2,
+    CFS_ERR_HIP = -3,          /* a HIP runtime call failed, see cfs_last_error()           */
+    CFS_ERR_NOT_SPD = -4,      /* QQ (symmetrised) is not positive definite                  */
+    CFS_ERR_DYNAMICS = -5,     /* sys_info.Aaug/Baug are not the double integrator of robot.A/B */
+    CFS_ERR_ALLOC = -6
+} cfs_error;
+
+/* per-problem status written by the solvers; the reference has no error convention
+ * (quadprog's exitflag is ignored, Lib/CFS_FANUC.m:85) -- an infeasible QP there crashes at
+ * Lib/CFS_FANUC.m:92; here it is reported. */
+typedef enum cfs_status {
+    CFS_OK_CONVERGED = 0,  /* "Converged at stepN"  (Lib/EVAL.m:65-67) */
+    CFS_OK_MAXITER = 1,    /* "MAX_ITER"            (Lib/EVAL.m:69-72) */
+    CFS_QP_INFEASIBLE = 2, /* the linearised constraints of some outer iteration are infeasible */
+    CFS_NUMERIC = 3        /* the active-set solver gave up (iteration cap / breakdown)      */
+} cfs_status;
+
+/* which dist_arm_* the class constructor selects (Lib/CFS_FANUC.m:49-54) */
+typedef enum cfs_robot_kind {
+    CFS_ROBOT_M16IB = 0, /* Lib/M16iB/dist_arm_3D_Heu_2.m : DH chain (Lib/functions/CapPos.m)            */
+    CFS_ROBOT_M200I = 1, /* Lib/200i/dist_arm_3D_200i_2.m : DH chain with theta(2) - pi/2 (:11)           */
+    CFS_ROBOT_2L = 2     /* Lib/2L/dist_arm_2L.m + Lib/2L/CapPos2.m : planar Rz chain with robot.T        */
+} cfs_robot_kind;
+
+typedef enum cfs_mode {
+    CFS_MODE_CFS = 0,    /* Lib/CFS_FANUC.m    : QP with QQ, ff, bounds +-MAX_input, margin obs{j}.epsilon */
+    CFS_MODE_PSGCFS = 1  /* Lib/PSGCFS_FANUC.m : noisy gradient step + projection QP, margin obs{j}.D      */
+} cfs_mode;
+
+/* robot = the fields of robotproperty2(id) (Lib/functions/robotproperty2.m:1-153) the path reads */
+typedef struct cfs_robot {
+    int kind;                       /* cfs_robot_kind                                           */
+    int nlink;                      /* size(robot.DH,1)                                          */
+    double DH[CFS_MAX_LINKS * 4];   /* robot.DH, nlink x 4 COLUMN-MAJOR: DH[i + c*nlink]         */
+    double base[3];                 /* robot.base                                                */
+    double cap[CFS_MAX_LINKS * 6];  /* robot.cap{i+1}.p, 3x2 column-major each: cap[i*6 + k*3+r] */
+    double T[9];                    /* 2L only: robot.T, 3x3 column-major                        */
+    double delta_t;                 /* robot.delta_t                                             */
+} cfs_robot;
+
+/* problem family = everything in sys_info that does not change across the batch
+ * (main_FANUC.m:106-127): consumed by cfs_problem_create. */
+typedef struct cfs_problem_desc {
+    cfs_robot robot;        /* sys_info.robot                                                  */
+    int mode;               /* cfs_mode                                                        */
+    int H;                  /* sys_info.H       (<= CFS_MAX_H)                                 */
+    int njoint;             /* sys_info.njoint  (= sys_info.nu; nstate = 2*njoint)             */
+    int nobs;               /* size(obs,2)      (<= CFS_MAX_OBS)                               */
+    const double *QQ;       /* sys_info.QQ, nn x nn, nn = H*njoint                             */
+    const double *Aaug;     /* sys_info.Aaug, (H*nstate) x nstate; may be NULL (then implied)  */
+    const double *Baug;     /* sys_info.Baug, (H*nstate) x nn;     may be NULL (then implied)  */
+    const double *lim;      /* sys_info.lim, njoint                                            */
+    const double *MAX_input;/* sys_info.MAX_input, nn (CFS mode; ignored for PSGCFS)           */
+    const double *margin;   /* nobs: obs{j}.epsilon (CFS, CFS_FANUC.m:117) / obs{j}.D (PSGCFS_FANUC.m:158) */
+    double epsilon_O;       /* sys_info.epsilon_O                                              */
+    int MAX_O_ITER;         /* sys_info.MAX_O_ITER                                             */
+    double alpha;           /* sys_info.alpha (PSGCFS step, main_FANUC.m:120)                  */
+    int max_batch;          /* capacity B_max of the handle's device workspace                 */
+} cfs_problem_desc;
+
+typedef struct cfs_problem cfs_problem; /* opaque */
+
+/* per-batch inputs: what differs between the B problems (start/goal/obstacles/seeds) */
+typedef struct cfs_batch_in {
+    int B;
+    const double *x_init; /* B x (H*nstate): sys_info.x_  (stacked [theta;omega] of waypoints 1..H) */
+    const double *xR1;    /* B x nstate    : sys_info.xR(:,1)                                       */
+    const double *ff;     /* B x nn        : sys_info.ff                                            */
+    const double *caug;   /* B             : sys_info.caug                                          */
+    const double *obs;    /* B x nobs x 6  : [obs{j}.l(:,1); obs{j}.l(:,2)]                         */
+    const double *noise;  /* PSGCFS: B x noise_rows x nn draws of normrnd(0,0.1) (PSGCFS_FANUC.m:109),
+                             one row consumed per PSG step; NULL = zeros                            */
+    int noise_rows;
+} cfs_batch_in;
+
+/* per-batch outputs: what the callers read back (main_FANUC.m:144-162, RRTstar_CFS.m:197-203) */
+typedef struct cfs_batch_out {
+    double *u;           /* B x nn          : self.u                                   */
+    double *x_;          /* B x (H*nstate)  : self.x_                                  */
+    double *cost_all;    /* B x MAX_O_ITER  : self.eval.cost_all   (first iter_O-1 entries valid) */
+    double *e_cost_all;  /* B x MAX_O_ITER  : self.eval.e_cost_all                     */
+    double *e_u_all;     /* B x MAX_O_ITER  : self.eval.e_u_all                        */
+    int *iter_O;         /* B : self.iter_O (reference convention: iterations run = iter_O-1) */
+    int *total_iter;     /* B : self.total_iter (sum of active-set steps; stands in for quadprog's output.iterations) */
+    int *status;         /* B : cfs_status                                             */
+} cfs_batch_out;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int cfs_abi_version(void);
+const char *cfs_last_error(void);
+int cfs_device_count(void);                 /* number of HIP devices (0 without a GPU)  */
+int cfs_set_device(int device);             /* device used by subsequently created handles */
+
+/* ---- problem family handle ------------------------------------------------------------------
+ * replaces: the constructors CFS_FANUC(obs,sys_info,ROBOT) (Lib/CFS_FANUC.m:40-59) and
+ * PSGCFS_FANUC(obs,sys_info,ROBOT) (Lib/PSGCFS_FANUC.m:43-62) plus the once-per-solve setup
+ * quadprog does internally (factorising QQ).  Host pointers.  Validates Aaug/Baug against
+ * the double integrator of robot.A/robot.B (robotproperty2.m:136-139) when they are given. */
+int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out);
+void cfs_problem_destroy(cfs_problem *p);
+
+/* ---- whole solve -----------------------------------------------------------------------------
+ * replaces: self.optimizer() (Lib/CFS_FANUC.m:62-79, Lib/PSGCFS_FANUC.m:65-82) for B problems.
+ * Host pointers; copies in, runs all outer iterations on the device, copies out, synchronises. */
+int cfs_solve_batch(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out);
+
+/* Same with DEVICE pointers on `stream` (hipStream_t as void*), no synchronisation.
+ * in->B <= max_batch.  This is the entry bench.py times (inputs resident in HBM). */
+int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream);
+
+/* ---- pieces of the path (host pointers; for callers that drive the outer loop themselves and
+ *      for kernel-level parity tests) ------------------------------------------------------- */
+
+/* [d,linkid] = dist_arm_all(theta,base,obs{j}.l,robot) (Lib/CFS_FANUC.m:115 ->
+ * Lib/200i/dist_arm_3D_200i_2.m:1-30 | Lib/M16iB/dist_arm_3D_Heu_2.m | Lib/2L/dist_arm_2L.m)
+ * for N configurations x nobs obstacles.  theta: N x njoint; obs: nobs x 6;
+ * d: N x nobs; linkid: N x nobs (1-based); pos (optional): N x njoint x 6 capsule end points
+ * [pos{i}.p(:,1); pos{i}.p(:,2)] (Lib/functions/CapPos.m:18-20). */
+int cfs_dist_arm(const cfs_robot *robot, int njoint, int N, const double *theta, int nobs, const double *obs,
+                 double *d, int *linkid, double *pos);
+
+/* the distance/Jacobian half of get_con (Lib/CFS_FANUC.m:110-121): for every (problem, obstacle,
+ * waypoint) the distance, closest link and Diff = num_jac(f,theta)' (Lib/functions/num_jac.m:1-17,
+ * literal scheme).  x_: B x (H*nstate); obs: B x nobs x 6;
+ * dist: B x nobs x H; linkid: B x nobs x H; grad: B x nobs x H x njoint. */
+int cfs_linearize(cfs_problem *p, int B, const double *x_, const double *obs, double *dist, int *linkid, double *grad);
+
+/* self.get_con() with the reference's public dense outputs self.Ainq / self.binq
+ * (Lib/CFS_FANUC.m:101-135): rows = nobs*H*(1+2*njoint) in the reference's row order.
+ * x_: B x (H*nstate); u: B x nn; xR1: B x nstate; obs: B x nobs x 6;
+ * Ainq: B x (rows x nn column-major); binq: B x rows. */
+int cfs_get_con(cfs_problem *p, int B, const double *x_, const double *u, const double *xR1, const double *obs,
+                double *Ainq, double *binq);
+
+/* one QP of the path for B problems on given linearisation data (dist/grad as returned by
+ * cfs_linearize at u_lin): CFS mode  = quadprog(QQ,ff,Ainq,binq,[],[],-MAX_input,MAX_input)
+ * (Lib/CFS_FANUC.m:85); PSGCFS mode = quadprog(I,-u_,Ainq,binq) (Lib/PSGCFS_FANUC.m:117-120) with
+ * u_ passed in `lin`.  lin: B x nn (CFS: ff; PSGCFS: u_); u_lin: B x nn; xR1: B x nstate.
+ * Outputs u: B x nn; lambda (optional): B x (nobs*H + 4*nn) multipliers ordered
+ * [collision (j,i) | vel+ (i,c) | vel- (i,c) | bound+ | bound-]; qp_iter, status: B. */
+int cfs_qp(cfs_problem *p, int B, const double *lin, const double *u_lin, const double *xR1,
+           const double *dist, const double *grad, double *u, double *lambda, int *qp_iter, int *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFS_HIP_H */

@@ -1,0 +1,142 @@
+"""ctypes binding of libcfs_hip.so (the C ABI of include/cfs_hip.h).
+
+There is no CPU fallback: if the HIP library is missing this module raises at import of the
+symbols, and without a GPU every compute entry point returns CFS_ERR_NO_DEVICE, which
+``check()`` turns into ``CfsError``.
+
+``torch`` (when importable) is imported BEFORE the library is loaded so that the process holds
+one HIP runtime (both resolve the SONAME libamdhip64.so.7; see DESIGN.md "Process layout").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+try:  # plumbing only: device memory, streams, torch.distributed
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the host-pointer entry points
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcfs_hip.so")
+
+CFS_MAX_LINKS = 8
+CFS_MAX_OBS = 32
+CFS_MAX_H = 64
+
+CFS_SUCCESS = 0
+ERRORS = {-1: "CFS_ERR_INVALID_ARG", -2: "CFS_ERR_NO_DEVICE", -3: "CFS_ERR_HIP", -4: "CFS_ERR_NOT_SPD",
+          -5: "CFS_ERR_DYNAMICS", -6: "CFS_ERR_ALLOC"}
+STATUS = {0: "OK_CONVERGED", 1: "OK_MAXITER", 2: "QP_INFEASIBLE", 3: "NUMERIC"}
+ROBOT_KIND = {"M16iB": 0, "M200i": 1, "2L": 2}
+MODE = {"CFS": 0, "PSGCFS": 1}
+
+
+class CfsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class cfs_robot(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int),
+        ("nlink", C.c_int),
+        ("DH", C.c_double * (CFS_MAX_LINKS * 4)),
+        ("base", C.c_double * 3),
+        ("cap", C.c_double * (CFS_MAX_LINKS * 6)),
+        ("T", C.c_double * 9),
+        ("delta_t", C.c_double),
+    ]
+
+
+class cfs_problem_desc(C.Structure):
+    _fields_ = [
+        ("robot", cfs_robot),
+        ("mode", C.c_int),
+        ("H", C.c_int),
+        ("njoint", C.c_int),
+        ("nobs", C.c_int),
+        ("QQ", C.c_void_p),
+        ("Aaug", C.c_void_p),
+        ("Baug", C.c_void_p),
+        ("lim", C.c_void_p),
+        ("MAX_input", C.c_void_p),
+        ("margin", C.c_void_p),
+        ("epsilon_O", C.c_double),
+        ("MAX_O_ITER", C.c_int),
+        ("alpha", C.c_double),
+        ("max_batch", C.c_int),
+    ]
+
+
+class cfs_batch_in(C.Structure):
+    _fields_ = [
+        ("B", C.c_int),
+        ("x_init", C.c_void_p),
+        ("xR1", C.c_void_p),
+        ("ff", C.c_void_p),
+        ("caug", C.c_void_p),
+        ("obs", C.c_void_p),
+        ("noise", C.c_void_p),
+        ("noise_rows", C.c_int),
+    ]
+
+
+class cfs_batch_out(C.Structure):
+    _fields_ = [
+        ("u", C.c_void_p),
+        ("x_", C.c_void_p),
+        ("cost_all", C.c_void_p),
+        ("e_cost_all", C.c_void_p),
+        ("e_u_all", C.c_void_p),
+        ("iter_O", C.c_void_p),
+        ("total_iter", C.c_void_p),
+        ("status", C.c_void_p),
+    ]
+
+
+# every symbol include/cfs_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("cfs_abi_version", C.c_int, []),
+    ("cfs_last_error", C.c_char_p, []),
+    ("cfs_device_count", C.c_int, []),
+    ("cfs_set_device", C.c_int, [C.c_int]),
+    ("cfs_problem_create", C.c_int, [C.POINTER(cfs_problem_desc), C.POINTER(_P)]),
+    ("cfs_problem_destroy", None, [_P]),
+    ("cfs_solve_batch", C.c_int, [_P, C.POINTER(cfs_batch_in), C.POINTER(cfs_batch_out)]),
+    ("cfs_solve_batch_device", C.c_int, [_P, C.POINTER(cfs_batch_in), C.POINTER(cfs_batch_out), _P]),
+    ("cfs_dist_arm", C.c_int, [C.POINTER(cfs_robot), C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
+    ("cfs_linearize", C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
+    ("cfs_get_con", C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    ("cfs_qp", C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libcfs_hip.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C motionplanning_5d_m_amd/csrc)")
+        h = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(h, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != CFS_SUCCESS:
+        raise CfsError(rc, lib().cfs_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return int(lib().cfs_device_count())

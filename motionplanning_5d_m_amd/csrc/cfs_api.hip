@@ -1,0 +1,544 @@
+// cfs_api.hip -- host side of libcfs_hip.so: the C ABI declared in include/cfs_hip.h.
+// Owns the problem-family handle (device constants + workspace) and enqueues the kernels of one
+// solve on a caller-supplied stream without any host round trip inside the outer loop.
+#include "cfs_device.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+int g_device = 0;
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(CFS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int have_device()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void build_dev_robot(const cfs_robot &r, DevRobot &d)
+{
+    memset(&d, 0, sizeof d);
+    d.kind = r.kind;
+    d.nlink = r.nlink;
+    for (int i = 0; i < r.nlink && i < CFS_MAX_LINKS; ++i) {
+        d.dh_d[i] = r.DH[i + 1 * r.nlink];
+        d.dh_a[i] = r.DH[i + 2 * r.nlink];
+        const double al = r.DH[i + 3 * r.nlink];
+        d.ca[i] = cos(al);
+        d.sa[i] = sin(al);
+        d.th_off[i] = 0.0;
+        for (int e = 0; e < 6; ++e) d.cap[i * 6 + e] = r.cap[i * 6 + e];
+    }
+    if (r.kind == CFS_ROBOT_M200I) d.th_off[1] = M_PI / 2;   // dist_arm_3D_200i_2.m:11
+    for (int e = 0; e < 3; ++e) d.base[e] = r.base[e];
+    if (r.kind == CFS_ROBOT_2L)
+        for (int i = 0; i + 1 < 3 && i < CFS_MAX_LINKS; ++i)   // link i uses robot.T(:,i+2) (1-based), CapPos2.m:25
+            for (int e = 0; e < 3; ++e) d.t2l[i * 3 + e] = r.T[(i + 1) * 3 + e];
+}
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        n = count;
+        return hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T));
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+// device staging of host arrays for the host-pointer entry points
+struct Stage {
+    std::vector<void *> ptrs;
+    hipError_t err = hipSuccess;
+    template <class T> T *up(const T *h, size_t n)
+    {
+        if (err != hipSuccess) return nullptr;
+        void *d = nullptr;
+        err = hipMalloc(&d, (n ? n : 1) * sizeof(T));
+        if (err != hipSuccess) return nullptr;
+        ptrs.push_back(d);
+        if (h) err = hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice);
+        return static_cast<T *>(d);
+    }
+    template <class T> void down(T *h, const T *d, size_t n)
+    {
+        if (err == hipSuccess && h) err = hipMemcpy(h, d, n * sizeof(T), hipMemcpyDeviceToHost);
+    }
+    ~Stage() { for (void *q : ptrs) (void)hipFree(q); }
+};
+
+// symmetric positive definite inverse in extended precision (once per problem family)
+bool spd_inverse(int n, const double *Asym, std::vector<double> &inv)
+{
+    std::vector<long double> L((size_t)n * n, 0.0L), Li((size_t)n * n, 0.0L);
+    for (int j = 0; j < n; ++j) {
+        long double s = Asym[j + (size_t)j * n];
+        for (int k = 0; k < j; ++k) s -= L[j + (size_t)k * n] * L[j + (size_t)k * n];
+        if (!(s > 0)) return false;
+        const long double ljj = sqrtl(s);
+        L[j + (size_t)j * n] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            long double t = Asym[i + (size_t)j * n];
+            for (int k = 0; k < j; ++k) t -= L[i + (size_t)k * n] * L[j + (size_t)k * n];
+            L[i + (size_t)j * n] = t / ljj;
+        }
+    }
+    for (int j = 0; j < n; ++j) {          // Li = L^{-1}, lower
+        Li[j + (size_t)j * n] = 1.0L / L[j + (size_t)j * n];
+        for (int i = j + 1; i < n; ++i) {
+            long double s = 0.0L;
+            for (int k = j; k < i; ++k) s -= L[i + (size_t)k * n] * Li[k + (size_t)j * n];
+            Li[i + (size_t)j * n] = s / L[i + (size_t)i * n];
+        }
+    }
+    inv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {     // A^{-1} = Li' Li
+            long double s = 0.0L;
+            for (int k = i; k < n; ++k) s += Li[k + (size_t)i * n] * Li[k + (size_t)j * n];
+            inv[i + (size_t)j * n] = inv[j + (size_t)i * n] = (double)s;
+        }
+    return true;
+}
+
+}  // namespace
+
+struct cfs_problem {
+    cfs_problem_desc d;
+    int device;
+    int nn, ns, nx;
+    DevRobot hrobot;
+    DevBuf<DevRobot> rb;
+    DevBuf<double> QQ, Hinv, M1, M2, M3, lim, maxin, margin;
+    // workspace (max_batch problems)
+    DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg;
+    DevBuf<int> qp_status, qp_iter, noise_row, linkid;
+    DevBuf<unsigned char> done;
+    void release_all()
+    {
+        rb.release(); QQ.release(); Hinv.release(); M1.release(); M2.release(); M3.release();
+        lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
+        grad.release(); cost_new.release(); cost_old.release(); delta.release(); e_u.release();
+        Yg.release(); Tg.release(); qp_status.release(); qp_iter.release(); noise_row.release();
+        linkid.release(); done.release();
+    }
+};
+
+extern "C" {
+
+int cfs_abi_version(void) { return CFS_ABI_VERSION; }
+const char *cfs_last_error(void) { return g_err; }
+int cfs_device_count(void) { return have_device(); }
+
+int cfs_set_device(int device)
+{
+    const int n = have_device();
+    if (n == 0) return fail(CFS_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(CFS_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+    g_device = device;
+    return CFS_SUCCESS;
+}
+
+static int check_robot(const cfs_robot *r, int nj)
+{
+    if (!r) return fail(CFS_ERR_INVALID_ARG, "robot is NULL");
+    if (r->kind < CFS_ROBOT_M16IB || r->kind > CFS_ROBOT_2L) return fail(CFS_ERR_INVALID_ARG, "unknown robot kind %d", r->kind);
+    if (r->nlink < 1 || r->nlink > CFS_MAX_LINKS) return fail(CFS_ERR_INVALID_ARG, "robot.nlink %d outside 1..%d", r->nlink, CFS_MAX_LINKS);
+    if (nj < 1 || nj > 6 || nj > r->nlink) return fail(CFS_ERR_INVALID_ARG, "njoint %d unsupported (1..6, <= nlink)", nj);
+    if (r->kind == CFS_ROBOT_2L && nj > 2) return fail(CFS_ERR_INVALID_ARG, "the 2L model has 2 joints");
+    return CFS_SUCCESS;
+}
+
+int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
+{
+    if (!desc || !out) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    const int nj = desc->njoint, H = desc->H;
+    int rc = check_robot(&desc->robot, nj);
+    if (rc) return rc;
+    if (nj < 2) return fail(CFS_ERR_INVALID_ARG, "njoint %d unsupported (2..6)", nj);
+    if (H < 1 || H > CFS_MAX_H) return fail(CFS_ERR_INVALID_ARG, "H %d outside 1..%d", H, CFS_MAX_H);
+    if (desc->nobs < 1 || desc->nobs > CFS_MAX_OBS) return fail(CFS_ERR_INVALID_ARG, "nobs %d outside 1..%d", desc->nobs, CFS_MAX_OBS);
+    if (desc->mode != CFS_MODE_CFS && desc->mode != CFS_MODE_PSGCFS) return fail(CFS_ERR_INVALID_ARG, "unknown mode %d", desc->mode);
+    if (!desc->QQ || !desc->lim || !desc->margin) return fail(CFS_ERR_INVALID_ARG, "QQ/lim/margin must be given");
+    if (desc->mode == CFS_MODE_CFS && !desc->MAX_input) return fail(CFS_ERR_INVALID_ARG, "MAX_input must be given in CFS mode");
+    if (desc->max_batch < 1) return fail(CFS_ERR_INVALID_ARG, "max_batch must be >= 1");
+    if (desc->MAX_O_ITER < 0) return fail(CFS_ERR_INVALID_ARG, "MAX_O_ITER must be >= 0");
+    const double dt = desc->robot.delta_t;
+    if (!(dt > 0)) return fail(CFS_ERR_INVALID_ARG, "robot.delta_t must be positive");
+    const int nn = H * nj, ns = 2 * nj, nx = H * ns;
+
+    // sys_info.Aaug / Baug must be the double integrator of robot.A / robot.B
+    // (robotproperty2.m:136-139, main_FANUC.m:79-86): the kernels roll out with prefix sums.
+    if (desc->Baug) {
+        for (int i = 0; i < H; ++i)
+            for (int k = 0; k < H; ++k)
+                for (int r = 0; r < ns; ++r)
+                    for (int c = 0; c < nj; ++c) {
+                        double want = 0.0;
+                        if (k <= i && (r % nj) == c) want = r < nj ? ((double)(i - k) + 0.5) * dt * dt : dt;
+                        const double got = desc->Baug[(i * ns + r) + (size_t)(k * nj + c) * nx];
+                        if (fabs(got - want) > 1e-12 * (1.0 + fabs(want)))
+                            return fail(CFS_ERR_DYNAMICS, "Baug(%d,%d)=%.17g, double integrator expects %.17g", i * ns + r + 1, k * nj + c + 1, got, want);
+                    }
+    }
+    if (desc->Aaug) {
+        for (int i = 0; i < H; ++i)
+            for (int r = 0; r < ns; ++r)
+                for (int c = 0; c < ns; ++c) {
+                    double want = (r == c) ? 1.0 : 0.0;
+                    if (r < nj && c == r + nj) want = (double)(i + 1) * dt;
+                    const double got = desc->Aaug[(i * ns + r) + (size_t)c * nx];
+                    if (fabs(got - want) > 1e-12 * (1.0 + fabs(want)))
+                        return fail(CFS_ERR_DYNAMICS, "Aaug(%d,%d)=%.17g, double integrator expects %.17g", i * ns + r + 1, c + 1, got, want);
+                }
+    }
+    if (have_device() == 0) return fail(CFS_ERR_NO_DEVICE, "no HIP device visible");
+
+    // H^{-1} of the QP Hessian: QQ symmetrised (quadprog does so silently) for CFS, identity for the
+    // PSGCFS projection (PSGCFS_FANUC.m:117)
+    std::vector<double> Hinv;
+    {
+        std::vector<double> sym((size_t)nn * nn);
+        for (int j = 0; j < nn; ++j)
+            for (int i = 0; i < nn; ++i) sym[i + (size_t)j * nn] = 0.5 * (desc->QQ[i + (size_t)j * nn] + desc->QQ[j + (size_t)i * nn]);
+        if (!spd_inverse(nn, sym.data(), Hinv)) return fail(CFS_ERR_NOT_SPD, "QQ is not positive definite");
+    }
+    std::vector<double> Hq;   // Hessian inverse used by the QP
+    if (desc->mode == CFS_MODE_CFS) Hq = Hinv;
+    else {
+        Hq.assign((size_t)nn * nn, 0.0);
+        for (int i = 0; i < nn; ++i) Hq[i + (size_t)i * nn] = 1.0;
+    }
+    // family matrices in the gather layout [column (i*,c)][c'][i']
+    std::vector<double> M1((size_t)nn * nn), M2((size_t)nn * nn), M3((size_t)nn * nn);
+    {
+        std::vector<long double> a1(nn), a2(nn);
+        for (int c = 0; c < nj; ++c)
+            for (int i = 0; i < H; ++i) {
+                for (int r = 0; r < nn; ++r) {
+                    long double s1 = 0.0L, s2 = 0.0L;
+                    for (int k = 0; k <= i; ++k) {
+                        const long double h = Hq[r + (size_t)(k * nj + c) * nn];
+                        s1 += ((long double)(i - k) + 0.5L) * (long double)dt * (long double)dt * h;
+                        s2 += (long double)dt * h;
+                    }
+                    a1[r] = s1; a2[r] = s2;
+                }
+                const int col = i * nj + c;
+                for (int ip = 0; ip < H; ++ip)
+                    for (int cp = 0; cp < nj; ++cp) {
+                        const size_t o = ((size_t)col * nj + cp) * H + ip;
+                        M1[o] = (double)a1[ip * nj + cp];
+                        M2[o] = (double)a2[ip * nj + cp];
+                        M3[o] = Hq[(ip * nj + cp) + (size_t)col * nn];
+                    }
+            }
+    }
+
+    cfs_problem *p = new (std::nothrow) cfs_problem();
+    if (!p) return fail(CFS_ERR_ALLOC, "out of host memory");
+    p->d = *desc;
+    p->d.QQ = p->d.Aaug = p->d.Baug = p->d.lim = p->d.MAX_input = p->d.margin = nullptr;
+    p->device = g_device;
+    p->nn = nn; p->ns = ns; p->nx = nx;
+    build_dev_robot(desc->robot, p->hrobot);
+    const size_t Bm = (size_t)desc->max_batch;
+    hipError_t e = hipSetDevice(p->device);
+#define A_(buf, count) if (e == hipSuccess) e = p->buf.alloc(count)
+    A_(rb, 1); A_(QQ, (size_t)nn * nn); A_(Hinv, (size_t)nn * nn); A_(M1, (size_t)nn * nn); A_(M2, (size_t)nn * nn);
+    A_(M3, (size_t)nn * nn); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
+    A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
+    A_(cost_new, Bm); A_(cost_old, Bm); A_(delta, Bm); A_(e_u, Bm); A_(Yg, Bm * nn * nn); A_(Tg, Bm * nn * nn);
+    A_(qp_status, Bm); A_(qp_iter, Bm); A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H); A_(done, Bm);
+#undef A_
+#define U_(buf, src, count) if (e == hipSuccess) e = hipMemcpy(p->buf.p, src, (count) * sizeof(*p->buf.p), hipMemcpyHostToDevice)
+    U_(rb, &p->hrobot, 1); U_(QQ, desc->QQ, (size_t)nn * nn); U_(Hinv, Hinv.data(), (size_t)nn * nn);
+    U_(M1, M1.data(), (size_t)nn * nn); U_(M2, M2.data(), (size_t)nn * nn); U_(M3, M3.data(), (size_t)nn * nn);
+    U_(lim, desc->lim, nj); U_(margin, desc->margin, desc->nobs);
+    if (desc->mode == CFS_MODE_CFS) { U_(maxin, desc->MAX_input, nn); }
+    else if (e == hipSuccess) e = hipMemset(p->maxin.p, 0, nn * sizeof(double));
+#undef U_
+    if (e != hipSuccess) {
+        p->release_all();
+        delete p;
+        return fail(CFS_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return CFS_SUCCESS;
+}
+
+void cfs_problem_destroy(cfs_problem *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    p->release_all();
+    delete p;
+}
+
+static void fill_qp_common(const cfs_problem *p, QpParams &q, int B)
+{
+    memset(&q, 0, sizeof q);
+    q.B = B; q.H = p->d.H; q.nobs = p->d.nobs; q.mode = p->d.mode;
+    q.has_bounds = p->d.mode == CFS_MODE_CFS;
+    q.dt = p->d.robot.delta_t; q.alpha = p->d.alpha;
+    q.M1 = p->M1.p; q.M2 = p->M2.p; q.M3 = p->M3.p;
+    q.lim = p->lim.p; q.maxin = p->maxin.p; q.margin = p->margin.p;
+    q.dist = p->dist.p; q.grad = p->grad.p;
+    q.qp_status = p->qp_status.p; q.qp_iter = p->qp_iter.p;
+    q.Yg = p->Yg.p; q.Tg = p->Tg.p;
+}
+
+int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream)
+{
+    if (!p || !in || !out) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    const int B = in->B;
+    if (B < 1 || B > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "B=%d outside 1..max_batch=%d", B, p->d.max_batch);
+    if (!in->x_init || !in->xR1 || !in->ff || !in->caug || !in->obs) return fail(CFS_ERR_INVALID_ARG, "NULL input array");
+    if (!out->u || !out->x_ || !out->cost_all || !out->e_cost_all || !out->e_u_all || !out->iter_O || !out->total_iter || !out->status)
+        return fail(CFS_ERR_INVALID_ARG, "NULL output array");
+    HIPCHK(hipSetDevice(p->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nj = p->d.njoint, nn = p->nn, nx = p->nx, K = p->d.MAX_O_ITER;
+
+    InitParams ip;
+    ip.B = B; ip.nn = nn; ip.nx = nx; ip.mode = p->d.mode; ip.max_o_iter = K; ip.epsilon_O = p->d.epsilon_O;
+    ip.x_init = in->x_init; ip.caug = in->caug; ip.x_ = out->x_; ip.u = out->u; ip.qu = p->qu.p;
+    ip.cost_new = p->cost_new.p; ip.cost_old = p->cost_old.p; ip.iter_O = out->iter_O; ip.total_iter = out->total_iter;
+    ip.status = out->status; ip.noise_row = p->noise_row.p; ip.done = p->done.p;
+    launch_init(ip, s);
+    if (p->d.mode == CFS_MODE_CFS) {     // unconstrained minimiser -H^{-1} ff, constant over the outer loop
+        GemvParams g;
+        g.B = B; g.nn = nn; g.M = p->Hinv.p; g.X = in->ff; g.Y = p->x0.p; g.scale = -1.0;
+        launch_batched_gemv(g, s);
+    }
+    LinParams lp;
+    lp.rb = p->rb.p; lp.B = B; lp.H = p->d.H; lp.nobs = p->d.nobs; lp.x_ = out->x_; lp.obs = in->obs;
+    lp.done = p->done.p; lp.dist = p->dist.p; lp.linkid = nullptr; lp.grad = p->grad.p;
+    QpParams qp;
+    fill_qp_common(p, qp, B);
+    qp.x0 = p->x0.p; qp.ff = in->ff; qp.qu = p->qu.p; qp.noise = in->noise; qp.noise_rows = in->noise ? in->noise_rows : 0;
+    qp.xR1 = in->xR1; qp.u = out->u; qp.x_ = out->x_; qp.done = p->done.p; qp.iter_O = out->iter_O;
+    qp.noise_row = p->noise_row.p; qp.cost_new = p->cost_new.p; qp.cost_old_in = p->cost_old.p; qp.cost_old_out = p->cost_old.p;
+    qp.delta = p->delta.p; qp.e_u = p->e_u.p; qp.lambda = nullptr;
+    OuterParams op;
+    op.B = B; op.nn = nn; op.nx = nx; op.mode = p->d.mode; op.max_o_iter = K; op.epsilon_O = p->d.epsilon_O;
+    op.QQ = p->QQ.p; op.u = out->u; op.ff = in->ff; op.caug = in->caug; op.qu = p->qu.p;
+    op.qp_status = p->qp_status.p; op.qp_iter = p->qp_iter.p; op.delta = p->delta.p; op.e_u = p->e_u.p;
+    op.cost_new = p->cost_new.p; op.cost_old = p->cost_old.p; op.iter_O = out->iter_O; op.total_iter = out->total_iter;
+    op.status = out->status; op.done = p->done.p; op.cost_all = out->cost_all; op.e_cost_all = out->e_cost_all; op.e_u_all = out->e_u_all;
+    for (int it = 0; it < K; ++it) {     // problems that are done skip inside the kernels
+        launch_linearize(nj, lp, s);
+        launch_qp(nj, qp, false, s);
+        launch_qp(nj, qp, true, s);
+        launch_outer_update(op, s);
+    }
+    HIPCHK(hipGetLastError());
+    return CFS_SUCCESS;
+}
+
+int cfs_solve_batch(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out)
+{
+    if (!p || !in || !out) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    const int B = in->B;
+    if (B < 1 || B > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "B=%d outside 1..max_batch=%d", B, p->d.max_batch);
+    if (!in->x_init || !in->xR1 || !in->ff || !in->caug || !in->obs) return fail(CFS_ERR_INVALID_ARG, "NULL input array");
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nn = p->nn, nx = p->nx, ns = p->ns, K = p->d.MAX_O_ITER, nobs = p->d.nobs;
+    Stage st;
+    cfs_batch_in din = *in;
+    din.x_init = st.up(in->x_init, B * nx);
+    din.xR1 = st.up(in->xR1, B * ns);
+    din.ff = st.up(in->ff, B * nn);
+    din.caug = st.up(in->caug, B);
+    din.obs = st.up(in->obs, B * nobs * 6);
+    din.noise = in->noise ? st.up(in->noise, (size_t)B * in->noise_rows * nn) : nullptr;
+    cfs_batch_out dout;
+    dout.u = st.up<double>(nullptr, B * nn);
+    dout.x_ = st.up<double>(nullptr, B * nx);
+    dout.cost_all = st.up<double>(nullptr, B * K);
+    dout.e_cost_all = st.up<double>(nullptr, B * K);
+    dout.e_u_all = st.up<double>(nullptr, B * K);
+    dout.iter_O = st.up<int>(nullptr, B);
+    dout.total_iter = st.up<int>(nullptr, B);
+    dout.status = st.up<int>(nullptr, B);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    HIPCHK(hipMemset(dout.cost_all, 0, B * K * sizeof(double)));
+    HIPCHK(hipMemset(dout.e_cost_all, 0, B * K * sizeof(double)));
+    HIPCHK(hipMemset(dout.e_u_all, 0, B * K * sizeof(double)));
+    int rc = cfs_solve_batch_device(p, &din, &dout, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    st.down(out->u, dout.u, B * nn);
+    st.down(out->x_, dout.x_, B * nx);
+    st.down(out->cost_all, dout.cost_all, B * K);
+    st.down(out->e_cost_all, dout.e_cost_all, B * K);
+    st.down(out->e_u_all, dout.e_u_all, B * K);
+    st.down(out->iter_O, dout.iter_O, B);
+    st.down(out->total_iter, dout.total_iter, B);
+    st.down(out->status, dout.status, B);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+int cfs_dist_arm(const cfs_robot *robot, int njoint, int N, const double *theta, int nobs, const double *obs,
+                 double *d, int *linkid, double *pos)
+{
+    int rc = check_robot(robot, njoint);
+    if (rc) return rc;
+    if (N < 0 || nobs < 0 || !theta || !obs || !d) return fail(CFS_ERR_INVALID_ARG, "bad argument");
+    if (N == 0 || nobs == 0) return CFS_SUCCESS;
+    if (have_device() == 0) return fail(CFS_ERR_NO_DEVICE, "no HIP device visible");
+    HIPCHK(hipSetDevice(g_device));
+    DevRobot hr;
+    build_dev_robot(*robot, hr);
+    Stage st;
+    DistArmParams P;
+    P.rb = st.up(&hr, 1);
+    P.N = N; P.nobs = nobs; P.nj = njoint;
+    P.theta = st.up(theta, (size_t)N * njoint);
+    P.obs = st.up(obs, (size_t)nobs * 6);
+    P.d = st.up<double>(nullptr, (size_t)N * nobs);
+    P.linkid = st.up<int>(nullptr, (size_t)N * nobs);
+    P.pos = pos ? st.up<double>(nullptr, (size_t)N * njoint * 6) : nullptr;
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    launch_dist_arm(P, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    st.down(d, P.d, (size_t)N * nobs);
+    st.down(linkid, P.linkid, (size_t)N * nobs);
+    if (pos) st.down(pos, P.pos, (size_t)N * njoint * 6);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+static int check_batch(const cfs_problem *p, int B)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    if (B < 1 || B > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "B=%d outside 1..max_batch=%d", B, p->d.max_batch);
+    return CFS_SUCCESS;
+}
+
+int cfs_linearize(cfs_problem *p, int B, const double *x_, const double *obs, double *dist, int *linkid, double *grad)
+{
+    int rc = check_batch(p, B);
+    if (rc) return rc;
+    if (!x_ || !obs || !dist || !grad) return fail(CFS_ERR_INVALID_ARG, "NULL array");
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nobs = p->d.nobs, H = p->d.H, nj = p->d.njoint;
+    Stage st;
+    LinParams lp;
+    lp.rb = p->rb.p; lp.B = B; lp.H = p->d.H; lp.nobs = p->d.nobs;
+    lp.x_ = st.up(x_, (size_t)B * p->nx);
+    lp.obs = st.up(obs, (size_t)B * nobs * 6);
+    lp.done = nullptr; lp.dist = p->dist.p; lp.linkid = p->linkid.p; lp.grad = p->grad.p;
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    launch_linearize(p->d.njoint, lp, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    st.down(dist, p->dist.p, (size_t)B * nobs * H);
+    st.down(linkid, p->linkid.p, (size_t)B * nobs * H);
+    st.down(grad, p->grad.p, (size_t)B * nobs * H * nj);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+int cfs_get_con(cfs_problem *p, int B, const double *x_, const double *u, const double *xR1, const double *obs,
+                double *Ainq, double *binq)
+{
+    int rc = check_batch(p, B);
+    if (rc) return rc;
+    if (!x_ || !u || !xR1 || !obs || !Ainq || !binq) return fail(CFS_ERR_INVALID_ARG, "NULL array");
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nobs = p->d.nobs, H = p->d.H, nj = p->d.njoint, nn = p->nn;
+    const size_t rows = nobs * H * (1 + 2 * nj);
+    Stage st;
+    LinParams lp;
+    lp.rb = p->rb.p; lp.B = B; lp.H = p->d.H; lp.nobs = p->d.nobs;
+    lp.x_ = st.up(x_, (size_t)B * p->nx);
+    lp.obs = st.up(obs, (size_t)B * nobs * 6);
+    lp.done = nullptr; lp.dist = p->dist.p; lp.linkid = nullptr; lp.grad = p->grad.p;
+    DenseConParams dc;
+    dc.B = B; dc.H = p->d.H; dc.nj = p->d.njoint; dc.nobs = p->d.nobs; dc.dt = p->d.robot.delta_t;
+    dc.dist = p->dist.p; dc.grad = p->grad.p;
+    dc.u = st.up(u, (size_t)B * nn);
+    dc.xR1 = st.up(xR1, (size_t)B * p->ns);
+    dc.lim = p->lim.p; dc.margin = p->margin.p;
+    dc.Ainq = st.up<double>(nullptr, (size_t)B * rows * nn);
+    dc.binq = st.up<double>(nullptr, (size_t)B * rows);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    launch_linearize(p->d.njoint, lp, nullptr);
+    launch_dense_con(dc, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    st.down(Ainq, dc.Ainq, (size_t)B * rows * nn);
+    st.down(binq, dc.binq, (size_t)B * rows);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+int cfs_qp(cfs_problem *p, int B, const double *lin, const double *u_lin, const double *xR1,
+           const double *dist, const double *grad, double *u, double *lambda, int *qp_iter, int *status)
+{
+    int rc = check_batch(p, B);
+    if (rc) return rc;
+    if (!lin || !u_lin || !xR1 || !dist || !grad || !u) return fail(CFS_ERR_INVALID_ARG, "NULL array");
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nobs = p->d.nobs, H = p->d.H, nj = p->d.njoint, nn = p->nn;
+    const size_t nlam = nobs * H + 4 * nn;
+    Stage st;
+    double *d_lin = st.up(lin, (size_t)B * nn);
+    double *d_u = st.up(u_lin, (size_t)B * nn);
+    QpParams qp;
+    fill_qp_common(p, qp, B);
+    qp.mode = CFS_MODE_CFS;               // prologue: start from x0 (CFS: -H^{-1}ff, PSGCFS: u_ itself)
+    qp.xR1 = st.up(xR1, (size_t)B * p->ns);
+    qp.u = d_u;
+    qp.lambda = lambda ? st.up<double>(nullptr, (size_t)B * nlam) : nullptr;
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    HIPCHK(hipMemcpy(p->dist.p, dist, (size_t)B * nobs * H * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->grad.p, grad, (size_t)B * nobs * H * nj * sizeof(double), hipMemcpyHostToDevice));
+    if (p->d.mode == CFS_MODE_CFS) {
+        GemvParams g;
+        g.B = B; g.nn = (int)nn; g.M = p->Hinv.p; g.X = d_lin; g.Y = p->x0.p; g.scale = -1.0;
+        launch_batched_gemv(g, nullptr);
+        qp.x0 = p->x0.p;
+    } else qp.x0 = d_lin;
+    launch_qp(p->d.njoint, qp, false, nullptr);
+    launch_qp(p->d.njoint, qp, true, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    st.down(u, d_u, (size_t)B * nn);
+    if (lambda) st.down(lambda, qp.lambda, (size_t)B * nlam);
+    st.down(qp_iter, p->qp_iter.p, (size_t)B);
+    st.down(status, p->qp_status.p, (size_t)B);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    if (status)
+        for (int b = 0; b < B; ++b) status[b] = status[b] == QP_OK ? CFS_OK_CONVERGED : (status[b] == QP_INFEASIBLE ? CFS_QP_INFEASIBLE : CFS_NUMERIC);
+    return CFS_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// cfs_device.h -- shared declarations of libcfs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cfs_hip.h"
+
+#define CFS_WAVE 64
+
+// Robot constants in the form the kernels consume (built on the host from cfs_robot).
+// cos/sin of the constant DH alpha are evaluated once on the host (CapPos.m:13-15 evaluates
+// them on every call; they are call-invariant).
+struct DevRobot {
+    int kind;                    // cfs_robot_kind
+    int nlink;
+    double dh_d[CFS_MAX_LINKS];  // DH(:,2)
+    double dh_a[CFS_MAX_LINKS];  // DH(:,3)
+    double ca[CFS_MAX_LINKS];    // cos(DH(:,4))
+    double sa[CFS_MAX_LINKS];    // sin(DH(:,4))
+    double th_off[CFS_MAX_LINKS];// subtracted from theta: pi/2 on joint 2 for M200i (dist_arm_3D_200i_2.m:11)
+    double base[3];
+    double cap[CFS_MAX_LINKS * 6];  // cap[i*6 + k*3 + r]
+    double t2l[CFS_MAX_LINKS * 3];  // 2L: translation of link i = robot.T(:,i+1)  (CapPos2.m:25)
+};
+static_assert(sizeof(DevRobot) % 8 == 0, "DevRobot is copied to LDS as doubles");
+
+// ---- K1: linearisation (distance + literal finite-difference Jacobian) -------------------------
+struct LinParams {
+    const DevRobot *rb;          // device copy
+    int B, H, nobs;
+    const double *x_;            // B x (H*2*NJ)
+    const double *obs;           // B x nobs x 6
+    const unsigned char *done;   // B, may be null: problems flagged done are skipped
+    double *dist;                // B x nobs x H
+    int *linkid;                 // B x nobs x H (may be null)
+    double *grad;                // B x nobs x H x NJ
+};
+void launch_linearize(int nj, const LinParams &p, hipStream_t s);
+size_t linearize_lds_bytes(int nj, int nobs);
+
+struct DistArmParams {
+    const DevRobot *rb;
+    int N, nobs, nj;
+    const double *theta;         // N x nj
+    const double *obs;           // nobs x 6
+    double *d;                   // N x nobs
+    int *linkid;                 // N x nobs
+    double *pos;                 // N x nj x 6 or null
+};
+void launch_dist_arm(const DistArmParams &p, hipStream_t s);
+
+struct DenseConParams {
+    int B, H, nj, nobs;
+    double dt;
+    const double *dist, *grad;   // as LinParams
+    const double *u;             // B x nn
+    const double *xR1;           // B x 2nj
+    const double *lim, *margin;
+    double *Ainq;                // B x rows x nn (column-major per problem)
+    double *binq;                // B x rows
+};
+void launch_dense_con(const DenseConParams &p, hipStream_t s);
+
+// ---- K2: batched strictly convex QP (dual active set) + rollout --------------------------------
+enum { QP_OK = 0, QP_INFEASIBLE = 2, QP_NUMERIC = 3, QP_OVERFLOW = 4, QP_SKIPPED = 5 };
+
+struct QpParams {
+    int B, H, nobs, mode;        // mode: cfs_mode
+    int has_bounds;              // CFS: 1, PSGCFS: 0
+    double dt, alpha;
+    // problem-family constants
+    const double *M1, *M2, *M3;  // [nn columns][NJ][H]: H^{-1}Bpos', H^{-1}Bvel', H^{-1}
+    const double *lim;           // NJ
+    const double *maxin;         // nn
+    const double *margin;        // nobs
+    // per problem
+    const double *x0;            // CFS: unconstrained minimiser -H^{-1}ff, B x nn (PSGCFS: unused)
+    const double *ff;            // B x nn (PSGCFS gradient step)
+    const double *qu;            // B x nn: QQ*u of the current u (PSGCFS gradient step)
+    const double *noise;         // B x noise_rows x nn or null
+    int noise_rows;
+    const double *xR1;           // B x 2NJ
+    const double *dist, *grad;   // from K1
+    double *u;                   // B x nn: in: linearisation point u_lin, out: new u
+    double *x_;                  // B x H*2NJ: in: old trajectory, out: rolled-out trajectory (may be null)
+    // per problem solver state (may be null for the bare cfs_qp entry point)
+    const unsigned char *done;
+    const int *iter_O;
+    int *noise_row;
+    const double *cost_new, *cost_old_in; // PSGCFS stop_inner test
+    double *cost_old_out;
+    double *delta;               // ||x_new - x_old||
+    double *e_u;                 // ||u_old - u||
+    int *qp_status;              // B
+    int *qp_iter;                // B (steps of this solve)
+    double *lambda;              // optional B x (nobs*H + 4nn)
+    // big-path scratch (global memory), used when the LDS capacity overflows
+    double *Yg;                  // B x nn x nn
+    double *Tg;                  // B x nn x nn
+};
+void launch_qp(int nj, const QpParams &p, bool big, hipStream_t s);
+
+// ---- K3: batched dense products on the matrix cores (fp64 MFMA) --------------------------------
+struct GemvParams {
+    int B, nn;
+    const double *M;             // nn x nn column-major
+    const double *X;             // B x nn
+    double *Y;                   // B x nn : Y[b] = scale * M * X[b]
+    double scale;
+};
+void launch_batched_gemv(const GemvParams &p, hipStream_t s);
+
+struct OuterParams {             // cost + stop test + history after the QP (EVAL.m:51-73)
+    int B, nn, nx, mode, max_o_iter;
+    double epsilon_O;
+    const double *QQ;            // raw sys_info.QQ
+    const double *u, *ff, *caug;
+    double *qu;                  // out: QQ*u
+    const int *qp_status, *qp_iter;
+    const double *delta, *e_u;
+    double *cost_new, *cost_old;
+    int *iter_O, *total_iter, *status;
+    unsigned char *done;
+    double *cost_all, *e_cost_all, *e_u_all;   // B x max_o_iter
+};
+void launch_outer_update(const OuterParams &p, hipStream_t s);
+
+struct InitParams {
+    int B, nn, nx, mode, max_o_iter;
+    double epsilon_O;
+    const double *x_init, *caug;
+    double *x_, *u, *qu, *cost_new, *cost_old;
+    int *iter_O, *total_iter, *status, *noise_row;
+    unsigned char *done;
+};
+void launch_init(const InitParams &p, hipStream_t s);

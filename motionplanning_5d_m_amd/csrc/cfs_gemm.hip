@@ -1,0 +1,143 @@
+// cfs_gemm.hip -- K3: the dense contractions of the path, on the fp64 matrix cores, and the
+// per-iteration bookkeeping of EVAL (rows a8, a9 in DESIGN.md).
+//
+// The only dense products left on the path once the constraint rows are kept in structured form
+// are "one nn x nn matrix times a batch of B vectors":
+//   -H^{-1} * ff_b            unconstrained minimiser of the CFS QP (once per solve)
+//   QQ * u_b                  get_cost (Lib/EVAL.m:51-53) and dcostArm_f (Lib/PSGCFS_FANUC.m:131-133)
+// i.e. an (nn x nn) x (nn x B) GEMM; it runs on v_mfma_f64_16x16x4_f64.  Everything else on the
+// path is not GEMM-shaped and stays on the vector ALU.
+#include "cfs_device.h"
+
+namespace {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int GEMV_RT = 2;       // 16-row output tiles per wavefront
+
+// Y[b][r] = scale * sum_c M[r + c*nn] * X[b][c].  One wavefront: 16 problems x GEMV_RT*16 rows.
+// MFMA operand maps (f64 16x16x4): lane l gives A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// D[row = (l>>4) + 4*reg][col = l&15].  Here D rows = output index r, D columns = problem b.
+__global__ __launch_bounds__(CFS_WAVE) void cfs_batched_gemv_kernel(GemvParams P)
+{
+    const int lane = threadIdx.x, nn = P.nn;
+    const int b0 = blockIdx.x * 16, r0 = blockIdx.y * (16 * GEMV_RT);
+    const int lj = lane & 15, lk = lane >> 4;
+    const int bj = b0 + lj;
+    const bool bok = bj < P.B;
+    const double *xrow = P.X + (size_t)(bok ? bj : 0) * nn;
+    v4f64 acc[GEMV_RT];
+#pragma unroll
+    for (int t = 0; t < GEMV_RT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < nn; c0 += 4) {
+        const int c = c0 + lk;
+        const double bfrag = (bok && c < nn) ? xrow[c] : 0.0;
+#pragma unroll
+        for (int t = 0; t < GEMV_RT; ++t) {
+            const int r = r0 + t * 16 + lj;
+            const double afrag = (r < nn && c < nn) ? P.M[r + (size_t)c * nn] : 0.0;
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag, bfrag, acc[t], 0, 0, 0);
+        }
+    }
+    if (!bok) return;
+#pragma unroll
+    for (int t = 0; t < GEMV_RT; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = r0 + t * 16 + lk + 4 * reg;
+            if (r < nn) P.Y[(size_t)bj * nn + r] = P.scale * acc[t][reg];
+        }
+}
+
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, CFS_WAVE);
+    return v;
+}
+
+// self.eval bookkeeping after Solve_QP / inner_PSG_5: get_cost, store_result, iter_O++, stop_outer
+// (Lib/CFS_FANUC.m:73-77, Lib/EVAL.m:51-73).  One wavefront per problem; qu = QQ*u is already there.
+__global__ __launch_bounds__(CFS_WAVE) void cfs_outer_update_kernel(OuterParams P)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, nn = P.nn;
+    if (P.done[b]) return;
+    const int st = P.qp_status[b];
+    if (st == QP_INFEASIBLE || st == QP_NUMERIC || st == QP_OVERFLOW) {
+        if (lane == 0) {
+            P.status[b] = (st == QP_INFEASIBLE) ? CFS_QP_INFEASIBLE : CFS_NUMERIC;
+            P.total_iter[b] += P.qp_iter[b];
+            P.done[b] = 1;
+        }
+        return;
+    }
+    double quad = 0.0, lin = 0.0;
+    for (int e = lane; e < nn; e += CFS_WAVE) {
+        const double ue = P.u[(size_t)b * nn + e];
+        quad += ue * P.qu[(size_t)b * nn + e];
+        lin += P.ff[(size_t)b * nn + e] * ue;
+    }
+    quad = wsum(quad);
+    lin = wsum(lin);
+    if (lane != 0) return;
+    const double cost = 0.5 * quad + lin + P.caug[b];      // EVAL.m:52
+    const int k = P.iter_O[b] - 1;
+    double cold;
+    if (P.mode == CFS_MODE_CFS) { cold = P.cost_new[b]; P.cost_old[b] = cold; }  // CFS_FANUC.m:67
+    else cold = P.cost_old[b];                             // set inside inner_PSG_5 (PSGCFS_FANUC.m:89)
+    P.cost_all[(size_t)b * P.max_o_iter + k] = cost;       // EVAL.m:56-58
+    P.e_cost_all[(size_t)b * P.max_o_iter + k] = fabs(cold - cost);
+    P.e_u_all[(size_t)b * P.max_o_iter + k] = P.e_u[b];
+    P.cost_new[b] = cost;
+    if (st != QP_SKIPPED) P.total_iter[b] += P.qp_iter[b];
+    const int it = k + 2;
+    P.iter_O[b] = it;                                      // CFS_FANUC.m:77
+    if (P.delta[b] < P.epsilon_O) { P.status[b] = CFS_OK_CONVERGED; P.done[b] = 1; }   // EVAL.m:64-68
+    else if (it > P.max_o_iter) { P.status[b] = CFS_OK_MAXITER; P.done[b] = 1; }       // EVAL.m:69-72
+}
+
+// constructor state (Lib/CFS_FANUC.m:55-58, Lib/EVAL.m:40-48) and the stop_outer test that precedes
+// the first iteration (CFS_FANUC.m:63-64)
+__global__ __launch_bounds__(CFS_WAVE) void cfs_init_kernel(InitParams P)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double d2 = 0.0;
+    for (int e = lane; e < P.nx; e += CFS_WAVE) {
+        const double v = P.x_init[(size_t)b * P.nx + e];
+        P.x_[(size_t)b * P.nx + e] = v;
+        d2 += (v - 1.0) * (v - 1.0);                        // x_old = ones (EVAL.m:47)
+    }
+    for (int e = lane; e < P.nn; e += CFS_WAVE) { P.u[(size_t)b * P.nn + e] = 0.0; P.qu[(size_t)b * P.nn + e] = 0.0; }
+    d2 = wsum(d2);
+    if (lane != 0) return;
+    P.cost_new[b] = P.caug[b];                              // get_cost(zeros) (CFS_FANUC.m:63)
+    P.cost_old[b] = 100000.0;                               // EVAL.m:29
+    P.iter_O[b] = 1;
+    P.total_iter[b] = 0;
+    P.noise_row[b] = 0;
+    int done = 0, st = CFS_OK_MAXITER;
+    if (sqrt(d2) < P.epsilon_O) { done = 1; st = CFS_OK_CONVERGED; }
+    else if (1 > P.max_o_iter) { done = 1; st = CFS_OK_MAXITER; }
+    P.status[b] = st;
+    P.done[b] = (unsigned char)done;
+}
+
+}  // namespace
+
+void launch_batched_gemv(const GemvParams &p, hipStream_t s)
+{
+    const dim3 grid((p.B + 15) / 16, (p.nn + 16 * GEMV_RT - 1) / (16 * GEMV_RT)), block(CFS_WAVE);
+    hipLaunchKernelGGL(cfs_batched_gemv_kernel, grid, block, 0, s, p);
+}
+
+void launch_outer_update(const OuterParams &p, hipStream_t s)
+{
+    GemvParams g;
+    g.B = p.B; g.nn = p.nn; g.M = p.QQ; g.X = p.u; g.Y = p.qu; g.scale = 1.0;
+    launch_batched_gemv(g, s);
+    hipLaunchKernelGGL(cfs_outer_update_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
+}
+
+void launch_init(const InitParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(cfs_init_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
+}

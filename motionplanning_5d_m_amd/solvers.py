@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's solver classes over the C ABI.
+
+``CFS_FANUC(obs, sys_info, ROBOT).optimizer()`` and ``PSGCFS_FANUC(obs, sys_info, ROBOT).optimizer()``
+keep the reference's names, argument meaning and result fields (Lib/CFS_FANUC.m:40-79,
+Lib/PSGCFS_FANUC.m:43-82, Lib/EVAL.m): ``u, x_, Ainq, binq, iter_O, total_iter, eval.cost_all,
+eval.e_cost_all, eval.e_u_all, eval.cost_new``.  Every numerical step happens in libcfs_hip.so on
+the GPU; this module only packs arguments.  ``CFSBatch`` is the batched form (the build's added
+outer dimension: stochastic seeds, RRT node pairs, start/goal/obstacle variations).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib
+from .robotproperty2 import to_c_robot
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if torch is not None and isinstance(a, torch.Tensor):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def obs_to_array(obs):
+    """obs cell -> (nobs, 6) rows [obs{j}.l(:,1); obs{j}.l(:,2)]."""
+    return _f64(np.stack([np.concatenate([np.asarray(o["l"], float)[:, 0], np.asarray(o["l"], float)[:, 1]]) for o in obs]))
+
+
+class CFSBatch:
+    """A problem family (robot, horizon, cost matrix, limits, obstacle count and margins) on one GPU,
+    solving batches of problems that differ in start/goal (x_init, xR1, ff, caug), obstacles and noise."""
+
+    def __init__(self, sys_info, nobs, margin, mode="CFS", max_batch=1, device=None, check_dynamics=True):
+        s = sys_info
+        self.mode = mode
+        self.H, self.nj = int(s.H), int(s.njoint)
+        self.ns, self.nn, self.nx = 2 * self.nj, self.H * self.nj, self.H * 2 * self.nj
+        self.nobs, self.K = int(nobs), int(s.MAX_O_ITER)
+        self.max_batch = int(max_batch)
+        self.robot = s.robot
+        self.rows = self.nobs * self.H * (1 + 2 * self.nj)
+        lib = _lib.lib()
+        if device is not None:
+            _lib.check(lib.cfs_set_device(int(device)))
+        d = _lib.cfs_problem_desc()
+        d.robot = to_c_robot(s.robot)
+        d.mode = _lib.MODE[mode]
+        d.H, d.njoint, d.nobs = self.H, self.nj, self.nobs
+        keep = [np.asfortranarray(s.QQ, dtype=np.float64), _f64(s.lim), _f64(np.asarray(margin, float).reshape(-1))]
+        d.QQ, d.lim, d.margin = _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2])
+        if keep[2].size != self.nobs:
+            raise ValueError("margin must have one entry per obstacle")
+        if check_dynamics and getattr(s, "Aaug", None) is not None:
+            keep.append(np.asfortranarray(s.Aaug, dtype=np.float64))
+            d.Aaug = _ptr(keep[-1])
+        if check_dynamics and getattr(s, "Baug", None) is not None:
+            keep.append(np.asfortranarray(s.Baug, dtype=np.float64))
+            d.Baug = _ptr(keep[-1])
+        if mode == "CFS":
+            keep.append(_f64(s.MAX_input))
+            d.MAX_input = _ptr(keep[-1])
+        d.epsilon_O, d.MAX_O_ITER, d.alpha = float(s.epsilon_O), self.K, float(getattr(s, "alpha", 0.0))
+        d.max_batch = self.max_batch
+        h = C.c_void_p()
+        _lib.check(lib.cfs_problem_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cfs_problem_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- whole solve ------------------------------------------------------------------------------
+    def solve(self, x_init, xR1, ff, caug, obs, noise=None):
+        """Host arrays in, host arrays out (cfs_solve_batch)."""
+        x_init, xR1, ff, caug, obs = _f64(x_init), _f64(xR1), _f64(ff), _f64(caug).reshape(-1), _f64(obs)
+        B = x_init.shape[0]
+        assert x_init.shape == (B, self.nx) and xR1.shape == (B, self.ns) and ff.shape == (B, self.nn)
+        assert caug.shape == (B,) and obs.shape == (B, self.nobs, 6)
+        i = _lib.cfs_batch_in()
+        i.B = B
+        i.x_init, i.xR1, i.ff, i.caug, i.obs = _ptr(x_init), _ptr(xR1), _ptr(ff), _ptr(caug), _ptr(obs)
+        if noise is not None:
+            noise = _f64(noise)
+            assert noise.ndim == 3 and noise.shape[0] == B and noise.shape[2] == self.nn
+            i.noise, i.noise_rows = _ptr(noise), noise.shape[1]
+        r = SimpleNamespace(u=np.zeros((B, self.nn)), x_=np.zeros((B, self.nx)), cost_all=np.zeros((B, self.K)),
+                            e_cost_all=np.zeros((B, self.K)), e_u_all=np.zeros((B, self.K)),
+                            iter_O=np.zeros(B, np.int32), total_iter=np.zeros(B, np.int32), status=np.zeros(B, np.int32))
+        o = _lib.cfs_batch_out()
+        o.u, o.x_, o.cost_all, o.e_cost_all, o.e_u_all = _ptr(r.u), _ptr(r.x_), _ptr(r.cost_all), _ptr(r.e_cost_all), _ptr(r.e_u_all)
+        o.iter_O, o.total_iter, o.status = _ptr(r.iter_O), _ptr(r.total_iter), _ptr(r.status)
+        _lib.check(self._lib.cfs_solve_batch(self._h, C.byref(i), C.byref(o)))
+        return r
+
+    def alloc_outputs(self, B, device):
+        """Device-resident output buffers (torch CUDA tensors) for solve_device."""
+        z = lambda *shape, dt=torch.float64: torch.zeros(*shape, dtype=dt, device=device)  # noqa: E731
+        return SimpleNamespace(u=z(B, self.nn), x_=z(B, self.nx), cost_all=z(B, self.K), e_cost_all=z(B, self.K),
+                               e_u_all=z(B, self.K), iter_O=z(B, dt=torch.int32), total_iter=z(B, dt=torch.int32),
+                               status=z(B, dt=torch.int32))
+
+    def solve_device(self, x_init, xR1, ff, caug, obs, noise=None, out=None, stream=None):
+        """torch CUDA tensors in/out; enqueues on `stream` (default: torch's current stream) and
+        returns without synchronising (cfs_solve_batch_device)."""
+        B = x_init.shape[0]
+        for t in (x_init, xR1, ff, caug, obs) + ((noise,) if noise is not None else ()):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        if out is None:
+            out = self.alloc_outputs(B, x_init.device)
+        i = _lib.cfs_batch_in()
+        i.B = B
+        i.x_init, i.xR1, i.ff, i.caug, i.obs = _ptr(x_init), _ptr(xR1), _ptr(ff), _ptr(caug), _ptr(obs)
+        if noise is not None:
+            i.noise, i.noise_rows = _ptr(noise), noise.shape[1]
+        o = _lib.cfs_batch_out()
+        o.u, o.x_, o.cost_all, o.e_cost_all, o.e_u_all = _ptr(out.u), _ptr(out.x_), _ptr(out.cost_all), _ptr(out.e_cost_all), _ptr(out.e_u_all)
+        o.iter_O, o.total_iter, o.status = _ptr(out.iter_O), _ptr(out.total_iter), _ptr(out.status)
+        if stream is None:
+            stream = torch.cuda.current_stream(x_init.device).cuda_stream
+        _lib.check(self._lib.cfs_solve_batch_device(self._h, C.byref(i), C.byref(o), C.c_void_p(stream)))
+        return out
+
+    # ---- pieces -----------------------------------------------------------------------------------
+    def linearize(self, x_, obs):
+        x_, obs = _f64(x_), _f64(obs)
+        B = x_.shape[0]
+        dist = np.zeros((B, self.nobs, self.H))
+        lid = np.zeros((B, self.nobs, self.H), np.int32)
+        grad = np.zeros((B, self.nobs, self.H, self.nj))
+        _lib.check(self._lib.cfs_linearize(self._h, B, _ptr(x_), _ptr(obs), _ptr(dist), _ptr(lid), _ptr(grad)))
+        return dist, lid, grad
+
+    def get_con(self, x_, u, xR1, obs):
+        x_, u, xR1, obs = _f64(x_), _f64(u), _f64(xR1), _f64(obs)
+        B = x_.shape[0]
+        A = np.zeros((B, self.nn, self.rows))  # per problem rows x nn column-major == (nn, rows) C-order
+        b = np.zeros((B, self.rows))
+        _lib.check(self._lib.cfs_get_con(self._h, B, _ptr(x_), _ptr(u), _ptr(xR1), _ptr(obs), _ptr(A), _ptr(b)))
+        return A.transpose(0, 2, 1), b
+
+    def qp(self, lin, u_lin, xR1, dist, grad, want_lambda=True):
+        lin, u_lin, xR1, dist, grad = _f64(lin), _f64(u_lin), _f64(xR1), _f64(dist), _f64(grad)
+        B = lin.shape[0]
+        u = np.zeros((B, self.nn))
+        lam = np.zeros((B, self.nobs * self.H + 4 * self.nn)) if want_lambda else None
+        it, st = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        _lib.check(self._lib.cfs_qp(self._h, B, _ptr(lin), _ptr(u_lin), _ptr(xR1), _ptr(dist), _ptr(grad), _ptr(u),
+                                    _ptr(lam), _ptr(it), _ptr(st)))
+        return u, lam, it, st
+
+
+def dist_arm(robot, theta, obs_l, want_pos=False):
+    """[d, linkid] = dist_arm_*(theta, base, obs_l, robot) for N configurations x nobs obstacle axes
+    (theta: (N, nj); obs_l: (nobs, 6))."""
+    theta, obs_l = _f64(np.atleast_2d(theta)), _f64(np.atleast_2d(obs_l))
+    N, nj = theta.shape
+    nobs = obs_l.shape[0]
+    d = np.zeros((N, nobs))
+    lid = np.zeros((N, nobs), np.int32)
+    pos = np.zeros((N, nj, 2, 3)) if want_pos else None
+    rb = to_c_robot(robot)
+    _lib.check(_lib.lib().cfs_dist_arm(C.byref(rb), nj, N, _ptr(theta), nobs, _ptr(obs_l), _ptr(d), _ptr(lid), _ptr(pos)))
+    return (d, lid, pos) if want_pos else (d, lid)
+
+
+class EVAL:
+    """Result holder with the reference's field names (Lib/EVAL.m:9-37)."""
+
+    def __init__(self, sys_info):
+        self.sys_info = sys_info
+        self.epsilon_O, self.MAX_O_ITER = sys_info.epsilon_O, sys_info.MAX_O_ITER
+        self.x_ = np.asarray(sys_info.x_, float).copy()
+        self.cost_all, self.e_cost_all, self.e_u_all = np.zeros(0), np.zeros(0), np.zeros(0)
+        self.cost_new = 0.0
+
+
+class _SolverBase:
+    MODE = "CFS"
+    MARGIN_KEY = "epsilon"
+
+    def __init__(self, obs, sys_info, ROBOT="M16iB", device=None):
+        self.obs, self.sys_info, self.ROBOT = obs, sys_info, ROBOT
+        if getattr(sys_info.robot, "name", ROBOT) != ROBOT:
+            raise ValueError(f"sys_info.robot is {sys_info.robot.name!r} but ROBOT={ROBOT!r}")
+        self.nn = sys_info.H * sys_info.nu
+        self.x_ = np.asarray(sys_info.x_, float).reshape(-1).copy()
+        self.u = np.zeros(self.nn)
+        self.Ainq = self.binq = None
+        self.eval = EVAL(sys_info)
+        self.iter_O, self.total_iter, self.status = 1, 0, None
+        self._batch = CFSBatch(sys_info, len(obs), [o[self.MARGIN_KEY] for o in obs], mode=self.MODE, max_batch=1,
+                               device=device)
+
+    def _args(self):
+        s = self.sys_info
+        xR1 = np.asarray(s.xR, float).reshape(s.nstate, -1)[:, 0]
+        return xR1[None], _f64(s.ff).reshape(1, -1), np.array([s.caug], float), obs_to_array(self.obs)[None]
+
+    def get_con(self):
+        """self.Ainq / self.binq at the current (x_, u): dense, reference row order."""
+        xR1, _, _, obs = self._args()
+        A, b = self._batch.get_con(self.x_[None], self.u[None], xR1, obs)
+        self.Ainq, self.binq = A[0], b[0]
+        return self
+
+    def optimizer(self, noise=None):
+        xR1, ff, caug, obs = self._args()
+        nz = None if noise is None else _f64(noise)[None]
+        r = self._batch.solve(np.asarray(self.sys_info.x_, float).reshape(1, -1), xR1, ff, caug, obs, noise=nz)
+        n = int(r.iter_O[0]) - 1
+        self.u, self.x_ = r.u[0], r.x_[0]
+        self.iter_O, self.total_iter, self.status = int(r.iter_O[0]), int(r.total_iter[0]), int(r.status[0])
+        self.eval.cost_all, self.eval.e_cost_all, self.eval.e_u_all = r.cost_all[0, :n], r.e_cost_all[0, :n], r.e_u_all[0, :n]
+        self.eval.cost_new = float(r.cost_all[0, n - 1]) if n > 0 else float(self.sys_info.caug)
+        self.eval.x_ = self.x_
+        if self.status == 0:
+            print(f"Converged at step{self.iter_O}")  # EVAL.m:66
+        elif self.status == 1:
+            print("MAX_ITER")  # EVAL.m:70
+        return self
+
+
+class CFS_FANUC(_SolverBase):
+    """Lib/CFS_FANUC.m -- margin obs{j}.epsilon, QP with QQ/ff and +-MAX_input bounds."""
+    MODE, MARGIN_KEY = "CFS", "epsilon"
+
+
+class PSGCFS_FANUC(_SolverBase):
+    """Lib/PSGCFS_FANUC.m -- margin obs{j}.D, noisy gradient step + projection.  The normrnd draws
+    (PSGCFS_FANUC.m:109) are passed in explicitly: optimizer(noise=(rows, nn) array of N(0, 0.1^2))."""
+    MODE, MARGIN_KEY = "PSGCFS", "D"
