@@ -132,14 +132,15 @@ struct cfs_problem {
     int nn, ns, nx;
     DevRobot hrobot;
     DevBuf<DevRobot> rb;
-    DevBuf<double> QQ, Hinv, M1, M2, M3, lim, maxin, margin;
+    DevBuf<double> QQ, Hinv, Hq, M1, M2, M3, M1n, M2n, lim, maxin, margin;
     // workspace (max_batch problems)
-    DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg;
+    DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg, Pt;
     DevBuf<int> qp_status, qp_iter, noise_row, linkid;
     DevBuf<unsigned char> done;
     void release_all()
     {
-        rb.release(); QQ.release(); Hinv.release(); M1.release(); M2.release(); M3.release();
+        rb.release(); QQ.release(); Hinv.release(); Hq.release(); M1.release(); M2.release(); M3.release();
+        M1n.release(); M2n.release(); Pt.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
         grad.release(); cost_new.release(); cost_old.release(); delta.release(); e_u.release();
         Yg.release(); Tg.release(); qp_status.release(); qp_iter.release(); noise_row.release();
@@ -147,7 +148,26 @@ struct cfs_problem {
     }
 };
 
+// developer aid (not part of the ABI header): trace the active-set steps of one problem of the next solves
+static double *g_dbg = nullptr;
+static int g_dbg_b = -1, g_dbg_cap = 0;
+
 extern "C" {
+
+int cfs_debug_trace_begin(int b, int cap)
+{
+    if (g_dbg) { (void)hipFree(g_dbg); g_dbg = nullptr; }
+    g_dbg_b = b; g_dbg_cap = cap;
+    if (cap <= 0) return 0;
+    if (hipMalloc(reinterpret_cast<void **>(&g_dbg), (size_t)(cap + 1) * 8 * sizeof(double)) != hipSuccess) return -1;
+    return hipMemset(g_dbg, 0, (size_t)(cap + 1) * 8 * sizeof(double)) == hipSuccess ? 0 : -1;
+}
+int cfs_debug_trace_read(double *out)   /* out: (cap+1)*8 doubles; out[0] = number of records */
+{
+    if (!g_dbg) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpy(out, g_dbg, (size_t)(g_dbg_cap + 1) * 8 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 
 int cfs_abi_version(void) { return CFS_ABI_VERSION; }
 const char *cfs_last_error(void) { return g_err; }
@@ -235,6 +255,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     }
     // family matrices in the gather layout [column (i*,c)][c'][i']
     std::vector<double> M1((size_t)nn * nn), M2((size_t)nn * nn), M3((size_t)nn * nn);
+    std::vector<double> M1n((size_t)nn * nn), M2n((size_t)nn * nn);   // same columns, natural row order (fused kernel)
     {
         std::vector<long double> a1(nn), a2(nn);
         for (int c = 0; c < nj; ++c)
@@ -249,6 +270,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
                     a1[r] = s1; a2[r] = s2;
                 }
                 const int col = i * nj + c;
+                for (int r = 0; r < nn; ++r) { M1n[r + (size_t)col * nn] = (double)a1[r]; M2n[r + (size_t)col * nn] = (double)a2[r]; }
                 for (int ip = 0; ip < H; ++ip)
                     for (int cp = 0; cp < nj; ++cp) {
                         const size_t o = ((size_t)col * nj + cp) * H + ip;
@@ -270,7 +292,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     hipError_t e = hipSetDevice(p->device);
 #define A_(buf, count) if (e == hipSuccess) e = p->buf.alloc(count)
     A_(rb, 1); A_(QQ, (size_t)nn * nn); A_(Hinv, (size_t)nn * nn); A_(M1, (size_t)nn * nn); A_(M2, (size_t)nn * nn);
-    A_(M3, (size_t)nn * nn); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
+    A_(M3, (size_t)nn * nn); A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * 64 * 160); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
     A_(cost_new, Bm); A_(cost_old, Bm); A_(delta, Bm); A_(e_u, Bm); A_(Yg, Bm * nn * nn); A_(Tg, Bm * nn * nn);
     A_(qp_status, Bm); A_(qp_iter, Bm); A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H); A_(done, Bm);
@@ -278,6 +300,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
 #define U_(buf, src, count) if (e == hipSuccess) e = hipMemcpy(p->buf.p, src, (count) * sizeof(*p->buf.p), hipMemcpyHostToDevice)
     U_(rb, &p->hrobot, 1); U_(QQ, desc->QQ, (size_t)nn * nn); U_(Hinv, Hinv.data(), (size_t)nn * nn);
     U_(M1, M1.data(), (size_t)nn * nn); U_(M2, M2.data(), (size_t)nn * nn); U_(M3, M3.data(), (size_t)nn * nn);
+    U_(M1n, M1n.data(), (size_t)nn * nn); U_(M2n, M2n.data(), (size_t)nn * nn); U_(Hq, Hq.data(), (size_t)nn * nn);
     U_(lim, desc->lim, nj); U_(margin, desc->margin, desc->nobs);
     if (desc->mode == CFS_MODE_CFS) { U_(maxin, desc->MAX_input, nn); }
     else if (e == hipSuccess) e = hipMemset(p->maxin.p, 0, nn * sizeof(double));
@@ -324,38 +347,26 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nj = p->d.njoint, nn = p->nn, nx = p->nx, K = p->d.MAX_O_ITER;
 
-    InitParams ip;
-    ip.B = B; ip.nn = nn; ip.nx = nx; ip.mode = p->d.mode; ip.max_o_iter = K; ip.epsilon_O = p->d.epsilon_O;
-    ip.x_init = in->x_init; ip.caug = in->caug; ip.x_ = out->x_; ip.u = out->u; ip.qu = p->qu.p;
-    ip.cost_new = p->cost_new.p; ip.cost_old = p->cost_old.p; ip.iter_O = out->iter_O; ip.total_iter = out->total_iter;
-    ip.status = out->status; ip.noise_row = p->noise_row.p; ip.done = p->done.p;
-    launch_init(ip, s);
-    if (p->d.mode == CFS_MODE_CFS) {     // unconstrained minimiser -H^{-1} ff, constant over the outer loop
+    if (p->d.mode == CFS_MODE_CFS) {     // unconstrained minimiser -H^{-1} ff (MFMA), constant over the outer loop
         GemvParams g;
         g.B = B; g.nn = nn; g.M = p->Hinv.p; g.X = in->ff; g.Y = p->x0.p; g.scale = -1.0;
         launch_batched_gemv(g, s);
     }
-    LinParams lp;
-    lp.rb = p->rb.p; lp.B = B; lp.H = p->d.H; lp.nobs = p->d.nobs; lp.x_ = out->x_; lp.obs = in->obs;
-    lp.done = p->done.p; lp.dist = p->dist.p; lp.linkid = nullptr; lp.grad = p->grad.p;
-    QpParams qp;
-    fill_qp_common(p, qp, B);
-    qp.x0 = p->x0.p; qp.ff = in->ff; qp.qu = p->qu.p; qp.noise = in->noise; qp.noise_rows = in->noise ? in->noise_rows : 0;
-    qp.xR1 = in->xR1; qp.u = out->u; qp.x_ = out->x_; qp.done = p->done.p; qp.iter_O = out->iter_O;
-    qp.noise_row = p->noise_row.p; qp.cost_new = p->cost_new.p; qp.cost_old_in = p->cost_old.p; qp.cost_old_out = p->cost_old.p;
-    qp.delta = p->delta.p; qp.e_u = p->e_u.p; qp.lambda = nullptr;
-    OuterParams op;
-    op.B = B; op.nn = nn; op.nx = nx; op.mode = p->d.mode; op.max_o_iter = K; op.epsilon_O = p->d.epsilon_O;
-    op.QQ = p->QQ.p; op.u = out->u; op.ff = in->ff; op.caug = in->caug; op.qu = p->qu.p;
-    op.qp_status = p->qp_status.p; op.qp_iter = p->qp_iter.p; op.delta = p->delta.p; op.e_u = p->e_u.p;
-    op.cost_new = p->cost_new.p; op.cost_old = p->cost_old.p; op.iter_O = out->iter_O; op.total_iter = out->total_iter;
-    op.status = out->status; op.done = p->done.p; op.cost_all = out->cost_all; op.e_cost_all = out->e_cost_all; op.e_u_all = out->e_u_all;
-    for (int it = 0; it < K; ++it) {     // problems that are done skip inside the kernels
-        launch_linearize(nj, lp, s);
-        launch_qp(nj, qp, false, s);
-        launch_qp(nj, qp, true, s);
-        launch_outer_update(op, s);
-    }
+    FusedParams fp;
+    memset(&fp, 0, sizeof fp);
+    fp.rb = p->rb.p; fp.B = B; fp.H = p->d.H; fp.nobs = p->d.nobs; fp.mode = p->d.mode;
+    fp.has_bounds = p->d.mode == CFS_MODE_CFS; fp.max_o_iter = K; fp.noise_rows = in->noise ? in->noise_rows : 0;
+    fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O;
+    fp.M1 = p->M1n.p; fp.M2 = p->M2n.p; fp.M3 = p->Hq.p; fp.QQ = p->QQ.p;
+    fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
+    fp.x_init = in->x_init; fp.xR1 = in->xR1; fp.ff = in->ff; fp.caug = in->caug; fp.obs = in->obs; fp.noise = in->noise;
+    fp.x0 = p->x0.p;
+    fp.u = out->u; fp.x_ = out->x_; fp.cost_all = out->cost_all; fp.e_cost_all = out->e_cost_all; fp.e_u_all = out->e_u_all;
+    fp.iter_O = out->iter_O; fp.total_iter = out->total_iter; fp.status = out->status;
+    fp.Yg = p->Yg.p; fp.Pt = p->Pt.p;
+    fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
+    (void)nx;
+    HIPCHK(launch_fused(nj, fp, s));
     HIPCHK(hipGetLastError());
     return CFS_SUCCESS;
 }

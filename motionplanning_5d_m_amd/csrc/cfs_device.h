@@ -124,6 +124,26 @@ struct OuterParams {             // cost + stop test + history after the QP (EVA
 };
 void launch_outer_update(const OuterParams &p, hipStream_t s);
 
+// ---- fused persistent solver: one workgroup owns one problem for its whole outer loop -----------
+struct FusedParams {
+    const DevRobot *rb;
+    int B, H, nobs, mode, has_bounds, max_o_iter, noise_rows;
+    int qy, lin_w;               // filled by launch_fused: Y rows held in LDS, waypoints per linearisation tile
+    double dt, alpha, epsilon_O;
+    const double *M1, *M2, *M3;  // nn x nn column-major: H^{-1}Bpos', H^{-1}Bvel', H^{-1} (natural row order)
+    const double *QQ;            // raw sys_info.QQ
+    const double *lim, *maxin, *margin;
+    const double *x_init, *xR1, *ff, *caug, *obs, *noise;
+    const double *x0;            // CFS: -H^{-1} ff  (B x nn)
+    double *u, *x_, *cost_all, *e_cost_all, *e_u_all;
+    int *iter_O, *total_iter, *status;
+    double *Yg;                  // B x nn x nn: Y rows beyond the LDS capacity
+    double *Pt;                  // B x 64 x 160: columns of the inverse Gram matrix beyond the register-resident 96
+    double *dbg;                 // optional trace: 8 doubles per active-set step of problem dbg_b (developer aid)
+    int dbg_b, dbg_cap;
+};
+hipError_t launch_fused(int nj, FusedParams p, hipStream_t s);
+
 struct InitParams {
     int B, nn, nx, mode, max_o_iter;
     double epsilon_O;

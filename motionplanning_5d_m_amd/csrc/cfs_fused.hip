@@ -1,0 +1,733 @@
+// cfs_fused.hip -- the whole optimizer() loop of one problem in ONE persistent workgroup.
+//
+// Reference behaviour restated (row a8 of DESIGN.md ties a1-a7, a9 together):
+//   Lib/CFS_FANUC.m:62-79      while ~stop_outer: get_con; Solve_QP; get_cost; store_result; iter_O++
+//   Lib/PSGCFS_FANUC.m:65-103  same with one projected stochastic-gradient step per outer iteration
+//   Lib/EVAL.m:51-73           cost, history, stop test
+//
+// MI355X mapping.  Problems of a batch are independent and very unequal (most converge in a few
+// outer iterations with a handful of active constraints; infeasible linearisations need ~200
+// active-set steps with up to nn active rows to be certified).  One 256-thread workgroup
+// therefore owns one problem for its whole life: no host round trip, no inter-problem barrier,
+// and the hardware's workgroup dispatcher load-balances the stragglers over the 256 CUs.
+//   * linearisation (FK variants, segment pairs, literal num_jac) as in cfs_geom.hip, tiled over
+//     waypoints, scratch aliased with the QP's Y storage;
+//   * QP: Goldfarb-Idnani dual active set in range-space form.  The inverse Gram matrix
+//     P = (N'H^{-1}N)^{-1} is kept EXPLICITLY, one row per thread in registers (it is symmetric,
+//     so column access is never needed); adding a constraint is a bordered rank-1 update,
+//     dropping one a rank-1 downdate + swap-with-last: every step is O(q) per thread with O(1)
+//     depth.  Each direction is polished by iterative refinement against the TRUE Gram matrix
+//     (structured dots n_a'z), which keeps the explicit inverse honest over hundreds of updates.
+//     Y = H^{-1}N rows live in LDS (first QY rows) and spill to global memory beyond;
+//   * rollouts are short prefix sums from LDS, wave reductions use DPP row shifts (no ds_bpermute).
+#include "cfs_geom_dev.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int FT = 256;                  // threads per workgroup
+constexpr double DEP_TOL_F = 1e-8;       // dependent if delta <= tol * n'H^{-1}n: above the eps*cond(H) noise floor of Y = H^{-1}N
+enum { CT_COL = 0, CT_VELP = 1, CT_VELM = 2, CT_BNDP = 3, CT_BNDM = 4 };
+__device__ __forceinline__ int mk_code(int type, int i, int jc) { return (type << 16) | (i << 8) | jc; }
+
+// ---- DPP helpers (gfx9 row shifts / row broadcasts) ---------------------------------------------
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_f64(double old, double src)
+{
+    const int rl = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, RM, 0xf, false);
+    const int rh = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, RM, 0xf, false);
+    return __hiloint2double(rh, rl);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_min(double v)      // all lanes receive the minimum
+{
+    v = fmin(v, dpp_f64<0x111, 0xf>(v, v));   // row_shr:1
+    v = fmin(v, dpp_f64<0x112, 0xf>(v, v));   // row_shr:2
+    v = fmin(v, dpp_f64<0x114, 0xf>(v, v));   // row_shr:4
+    v = fmin(v, dpp_f64<0x118, 0xf>(v, v));   // row_shr:8
+    v = fmin(v, dpp_f64<0x142, 0xa>(v, v));   // row_bcast:15 -> rows 1,3
+    v = fmin(v, dpp_f64<0x143, 0xc>(v, v));   // row_bcast:31 -> rows 2,3
+    return readlane_f64(v, 63);
+}
+__device__ __forceinline__ double wave_add(double v)      // all lanes receive the sum
+{
+    v += dpp_f64<0x111, 0xf>(0.0, v);
+    v += dpp_f64<0x112, 0xf>(0.0, v);
+    v += dpp_f64<0x114, 0xf>(0.0, v);
+    v += dpp_f64<0x118, 0xf>(0.0, v);
+    v += dpp_f64<0x142, 0xa>(0.0, v);
+    v += dpp_f64<0x143, 0xc>(0.0, v);
+    return readlane_f64(v, 63);
+}
+
+// block-wide argmin of (v, id): every thread returns the same pair.  red: >= 2*(FT/64) doubles.
+__device__ __forceinline__ void block_argmin(double &v, int &id, double *red, int tid)
+{
+    const double m = wave_min(v);
+    const unsigned long long hit = __ballot(v == m);
+    const int src = hit ? (int)__builtin_ctzll(hit) : 0;
+    const int mid = __builtin_amdgcn_readlane(id, src);
+    const int wv = tid >> 6;
+    __syncthreads();
+    if ((tid & 63) == 0) { red[wv] = m; reinterpret_cast<int *>(red + FT / 64)[wv] = mid; }
+    __syncthreads();
+    double bm = red[0];
+    int bi = reinterpret_cast<int *>(red + FT / 64)[0];
+#pragma unroll
+    for (int w = 1; w < FT / 64; ++w) {
+        const double om = red[w];
+        const int oi = reinterpret_cast<int *>(red + FT / 64)[w];
+        if (om < bm) { bm = om; bi = oi; }
+    }
+    v = bm; id = bi;
+}
+__device__ __forceinline__ double block_sum(double v, double *red, int tid)
+{
+    const double s = wave_add(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < FT / 64; ++w) t += red[w];
+    return t;
+}
+
+// (Bvel v, Bpos v) of the vector in buf[0..HN) -> buf[HN..2HN), buf[2HN..3HN)   (short prefix sums)
+template <int NJ>
+__device__ __forceinline__ void roll_lds(double *buf, int H, double dt, int tid)
+{
+    const int HN = H * NJ;
+    for (int k = tid; k < HN; k += FT) {
+        const int i = k / NJ, c = k - i * NJ;
+        double sv = 0.0, sp = 0.0, coef = (double)i + 0.5;
+        for (int ip = 0; ip <= i; ++ip) {
+            const double x = buf[ip * NJ + c];
+            sv += x;
+            sp += coef * x;
+            coef -= 1.0;
+        }
+        buf[HN + k] = dt * sv;
+        buf[2 * HN + k] = (dt * dt) * sp;
+    }
+}
+
+// inward normal of constraint `code` applied to a vector given as (v, Bvel v, Bpos v) in LDS
+template <int NJ>
+__device__ __forceinline__ double ndot(int code, const double *buf, const double *g, int H)
+{
+    const int type = code >> 16, i = (code >> 8) & 0xff, jc = code & 0xff, HN = H * NJ;
+    switch (type) {
+    case CT_COL: {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) s += g[(jc * H + i) * NJ + c] * buf[2 * HN + i * NJ + c];
+        return s;
+    }
+    case CT_VELP: return -buf[HN + i * NJ + jc];
+    case CT_VELM: return buf[HN + i * NJ + jc];
+    case CT_BNDP: return -buf[i * NJ + jc];
+    default: return buf[i * NJ + jc];
+    }
+}
+
+// slack b - a'x of constraint `code` at the iterate xs = (x, Bvel x, Bpos x); *bnd = its right-hand side
+template <int NJ>
+__device__ __forceinline__ double slack_of(int code, const double *xs, const double *g, const double *rhs,
+                                           const double *lim, const double *v0, const double *maxin, int H, double *bnd)
+{
+    const int type = code >> 16, i = (code >> 8) & 0xff, jc = code & 0xff, HN = H * NJ;
+    switch (type) {
+    case CT_COL: {
+        const double rh = rhs[jc * H + i];
+        double s = rh;
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) s += g[(jc * H + i) * NJ + c] * xs[2 * HN + i * NJ + c];
+        *bnd = rh;
+        return s;
+    }
+    case CT_VELP: { const double bb = lim[jc] - v0[jc]; *bnd = bb; return bb - xs[HN + i * NJ + jc]; }   // CFS_FANUC.m:127
+    case CT_VELM: { const double bb = lim[jc] + v0[jc]; *bnd = bb; return bb + xs[HN + i * NJ + jc]; }   // CFS_FANUC.m:129
+    case CT_BNDP: { const double bb = maxin[i * NJ + jc]; *bnd = bb; return bb - xs[i * NJ + jc]; }
+    default: { const double bb = maxin[i * NJ + jc]; *bnd = bb; return bb + xs[i * NJ + jc]; }
+    }
+}
+
+
+// ---- one row of the symmetric inverse Gram matrix P: columns [0,PR) in registers, [PR,QB) in global ---
+// tail layout: ptail[(b-PR)*QB + a] (thread a reads consecutive addresses).  Active constraints occupy
+// SLOTS of [0,qhi); a freed slot keeps a (numerically) zero row and column, so whole 8-column chunks are
+// processed unguarded and no column is ever written through a runtime register index.
+template <int PR, int QB>
+struct PRow {
+    double v[PR];
+    __device__ __forceinline__ void zero(double *ptail, int a, int q)
+    {
+#pragma unroll
+        for (int b = 0; b < PR; ++b) v[b] = 0.0;
+        for (int b = PR; b < q; ++b) ptail[(b - PR) * QB + a] = 0.0;
+    }
+    // sum_b P[a][b] * vec[b]
+    __device__ __forceinline__ double dot(const double *vec, const double *ptail, int a, int q) const
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int b0 = 0; b0 < PR; b0 += 8)
+            if (b0 < q) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) s += v[b0 + jj] * vec[b0 + jj];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        for (int b = PR; b < q; ++b) s += ptail[(b - PR) * QB + a] * vec[b];
+        return s;
+    }
+    // P[a][b] += alpha * vec[b]   (vec zero beyond q)
+    __device__ __forceinline__ void axpy(double alpha, const double *vec, double *ptail, int a, int q)
+    {
+#pragma unroll
+        for (int b0 = 0; b0 < PR; b0 += 8)
+            if (b0 < q) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[b0 + jj] += alpha * vec[b0 + jj];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        for (int b = PR; b < q; ++b) ptail[(b - PR) * QB + a] += alpha * vec[b];
+    }
+    // P[a][b] = (P[a][b] + alpha * vec[b]) * mask[b]   (mask is exactly 0 or 1: annihilates a freed column)
+    __device__ __forceinline__ void axpy_mask(double alpha, const double *vec, const double *mask, double *ptail, int a, int q)
+    {
+#pragma unroll
+        for (int b0 = 0; b0 < PR; b0 += 8)
+            if (b0 < q) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[b0 + jj] = (v[b0 + jj] + alpha * vec[b0 + jj]) * mask[b0 + jj];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        for (int b = PR; b < q; ++b) ptail[(b - PR) * QB + a] = (ptail[(b - PR) * QB + a] + alpha * vec[b]) * mask[b];
+    }
+    // P[a][b] = alpha * vec[b]
+    __device__ __forceinline__ void set_scaled(double alpha, const double *vec, double *ptail, int a, int q)
+    {
+#pragma unroll
+        for (int b0 = 0; b0 < PR; b0 += 8)
+            if (b0 < q) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[b0 + jj] = alpha * vec[b0 + jj];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        for (int b = PR; b < q; ++b) ptail[(b - PR) * QB + a] = alpha * vec[b];
+    }
+    // row -> LDS vector (entries [0,q))
+    __device__ __forceinline__ void store(double *dst, const double *ptail, int a, int q) const
+    {
+#pragma unroll
+        for (int b0 = 0; b0 < PR; b0 += 8)
+            if (b0 < q) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) dst[b0 + jj] = v[b0 + jj];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        for (int b = PR; b < q; ++b) dst[b] = ptail[(b - PR) * QB + a];
+    }
+};
+
+struct FusedLayout {      // LDS offsets in doubles, computed identically on host and device
+    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, red, small, mx, ptail, y, total_fixed;
+};
+__host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int QB, int PR)
+{
+    FusedLayout L;
+    const int HN = H * NJ, NS = 2 * NJ;
+    int o = 0;
+    L.rb = o; o += (int)(sizeof(DevRobot) / 8);
+    L.ob = o; o += nobs * 6;
+    L.x = o; o += H * NS;
+    L.u = o; o += HN;
+    L.qu = o; o += HN;
+    L.g = o; o += nobs * HN;
+    L.rhs = o; o += nobs * H;
+    L.xs = o; o += 3 * HN;
+    L.wb = o; o += 3 * HN;
+    L.zb = o; o += 3 * HN;
+    L.d = o; o += QB;
+    L.r = o; o += QB;
+    L.rho = o; o += QB;
+    L.lam = o; o += QB;
+    L.prow = o; o += QB;
+    L.act = o; o += (QB + 1) / 2;
+    L.fre = o; o += (QB + 1) / 2;          // stack of freed slots
+    L.flag = o; o += (nobs * H + 4 * HN + 7) / 8;
+    L.red = o; o += 16;
+    L.small = o; o += 4 * NJ + nobs;       // lim, v0, theta0 (2NJ), margin
+    L.mx = o; o += HN;                     // MAX_input
+    L.ptail = o;                           // (tail columns of P live in global scratch)
+    o = (o + 1) & ~1;
+    L.y = o;
+    L.total_fixed = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NJ, int QB>
+__global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
+{
+    constexpr int NS = 2 * NJ, NVT = nvt(NJ), NE = 2 * NJ + 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int H = P.H, nobs = P.nobs, HN = H * NJ, nn = HN, NX = H * NS;
+    const double dt = P.dt;
+    constexpr int PR = QB < 96 ? QB : 96;   // register-resident columns of each P row (rest: global scratch)
+    const FusedLayout L = fused_layout(NJ, H, nobs, QB, PR);
+    DevRobot *rb = reinterpret_cast<DevRobot *>(lds + L.rb);
+    double *s_ob = lds + L.ob, *s_x = lds + L.x, *s_u = lds + L.u, *s_qu = lds + L.qu, *s_g = lds + L.g;
+    double *s_rhs = lds + L.rhs, *xs = lds + L.xs, *wb = lds + L.wb, *zb = lds + L.zb;
+    double *s_d = lds + L.d, *s_r = lds + L.r, *s_rho = lds + L.rho, *s_lam = lds + L.lam, *s_prow = lds + L.prow;
+    int *s_act = reinterpret_cast<int *>(lds + L.act);
+    int *s_free = reinterpret_cast<int *>(lds + L.fre);
+    unsigned char *s_flag = reinterpret_cast<unsigned char *>(lds + L.flag);
+    double *red = lds + L.red;
+    double *s_lim = lds + L.small, *s_v0 = s_lim + NJ, *s_th0 = s_v0 + NJ, *s_margin = s_th0 + 2 * NJ;
+    double *s_mx = lds + L.mx;
+    double *s_pt = P.Pt + (size_t)b * (QB - PR) * QB;   // columns [PR,QB) of P, [b-PR][a]
+    double *s_Y = lds + L.y;                        // QY rows of HN doubles; linearisation scratch in between
+    const int QY = P.qy;
+    double *Yg = P.Yg + (size_t)b * nn * nn;
+    const int ncon = nobs * H + (P.has_bounds ? 4 : 2) * HN;
+    const int maxit = 8 * nn + 200;                  // the oracle's longest certificates take ~2 nn steps
+
+    // ---- constructor state (CFS_FANUC.m:55-58, EVAL.m:40-48) ------------------------------------
+    {
+        const double *src = reinterpret_cast<const double *>(P.rb);
+        for (int e = tid; e < (int)(sizeof(DevRobot) / 8); e += FT) lds[L.rb + e] = src[e];
+        for (int e = tid; e < nobs * 6; e += FT) s_ob[e] = P.obs[(size_t)b * nobs * 6 + e];
+        for (int e = tid; e < NX; e += FT) s_x[e] = P.x_init[(size_t)b * NX + e];
+        for (int e = tid; e < HN; e += FT) { s_u[e] = 0.0; s_qu[e] = 0.0; s_mx[e] = P.has_bounds ? P.maxin[e] : 0.0; }
+        if (tid < NJ) {
+            s_lim[tid] = P.lim[tid];
+            s_v0[tid] = P.xR1[(size_t)b * NS + NJ + tid];
+            s_th0[tid] = P.xR1[(size_t)b * NS + tid];
+        }
+        if (tid < nobs) s_margin[tid] = P.margin[tid];
+    }
+    __syncthreads();
+    double cost_new = P.caug[b], cost_old = 100000.0;      // get_cost(zeros) = caug; EVAL.m:29
+    int iter_O = 1, total_iter = 0, noise_row = 0, status = CFS_OK_MAXITER;
+    bool done = false;
+    {
+        double d2 = 0.0;
+        for (int e = tid; e < NX; e += FT) { const double v = s_x[e] - 1.0; d2 += v * v; }   // x_old = ones (EVAL.m:47)
+        d2 = block_sum(d2, red, tid);
+        if (sqrt(d2) < P.epsilon_O) { done = true; status = CFS_OK_CONVERGED; }
+        else if (iter_O > P.max_o_iter) { done = true; status = CFS_OK_MAXITER; }
+    }
+
+    PRow<PR, QB> Pr;                                       // row `tid` of P = (N'H^{-1}N)^{-1}
+
+    while (!done) {
+        // =========================================================================================
+        // get_con, distance half (CFS_FANUC.m:110-118): dist -> s_rhs, Diff -> s_g
+        // =========================================================================================
+        {
+            const int W = P.lin_w;
+            double *s_th = s_Y;                              // [W][NJ]
+            double *s_sc = s_th + W * NJ;                    // [W][NJ][3][2]
+            double *s_tm = s_sc + W * NJ * 6;                // [W][NVT][12]
+            double *s_en = s_tm + W * NVT * 12;              // [W][NVT][6]
+            double *s_dt = s_en + W * NVT * 6;               // [W][NVT][nobs]
+            for (int w0 = 0; w0 < H; w0 += W) {
+                const int Wc = min(W, H - w0);
+                for (int e = tid; e < Wc * NJ * 3; e += FT) {
+                    const int var = e % 3, m = (e / 3) % NJ, wi = e / (3 * NJ);
+                    double x = s_x[(w0 + wi) * NS + m];
+                    if (var == 1) x = x + FD_EPS / 2;        // num_jac.m:11
+                    else if (var == 2) x = x - FD_EPS / 2;   // num_jac.m:13
+                    x = x - rb->th_off[m];                   // dist_arm_3D_200i_2.m:11
+                    double sn, cs;
+                    sincos(x, &sn, &cs);
+                    s_sc[((wi * NJ + m) * 3 + var) * 2 + 0] = sn;
+                    s_sc[((wi * NJ + m) * 3 + var) * 2 + 1] = cs;
+                }
+                __syncthreads();
+                for (int k1 = 1; k1 <= NJ; ++k1) {
+                    const int nv = 2 * k1 + 1;
+                    for (int e = tid; e < Wc * nv; e += FT) {
+                        const int v = e % nv, wi = e / nv;
+                        const int avar = (v == 2 * k1 - 1) ? 1 : (v == 2 * k1 ? 2 : 0);
+                        const int pv = min(v, 2 * (k1 - 1));
+                        const double sn = s_sc[((wi * NJ + (k1 - 1)) * 3 + avar) * 2 + 0];
+                        const double cs = s_sc[((wi * NJ + (k1 - 1)) * 3 + avar) * 2 + 1];
+                        const double *par = (k1 == 1) ? nullptr : s_tm + (wi * NVT + kvoff(k1 - 1) + pv) * 12;
+                        double M[12], e6[6];
+                        fk_step(rb, k1 - 1, sn, cs, par, M);
+                        link_ends(rb, k1 - 1, M, e6);
+                        double *dstM = s_tm + (wi * NVT + kvoff(k1) + v) * 12;
+                        double *dstE = s_en + (wi * NVT + kvoff(k1) + v) * 6;
+#pragma unroll
+                        for (int qq = 0; qq < 12; ++qq) dstM[qq] = M[qq];
+#pragma unroll
+                        for (int qq = 0; qq < 6; ++qq) dstE[qq] = e6[qq];
+                    }
+                    __syncthreads();
+                }
+                for (int e = tid; e < NVT * Wc * nobs; e += FT) {
+                    const int j = e % nobs, wi = (e / nobs) % Wc, kv = e / (nobs * Wc);
+                    s_dt[(wi * NVT + kv) * nobs + j] = seg_seg_dist(s_en + (wi * NVT + kv) * 6, s_ob + j * 6);
+                }
+                __syncthreads();
+                for (int e = tid; e < Wc * nobs; e += FT) {
+                    const int j = e % nobs, wi = e / nobs;
+                    const double *tab = s_dt + (wi * NVT) * nobs + j;
+                    double dev[NE];
+#pragma unroll
+                    for (int ev = 0; ev < NE; ++ev) {
+                        double d = INFINITY;
+#pragma unroll
+                        for (int k1 = 1; k1 <= NJ; ++k1) {
+                            const double dis = tab[(kvoff(k1) + min(ev, 2 * k1)) * nobs];
+                            if (dis < d) d = dis;
+                        }
+                        dev[ev] = d;
+                    }
+                    s_rhs[j * H + w0 + wi] = dev[0];
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) s_g[(j * H + w0 + wi) * NJ + m] = (dev[2 * m + 1] - dev[2 * m + 2]) / FD_EPS;
+                }
+                __syncthreads();
+            }
+        }
+
+        // =========================================================================================
+        // the QP of this outer iteration (CFS_FANUC.m:85 | PSGCFS_FANUC.m:106-128)
+        // =========================================================================================
+        bool skip = false;
+        if (P.mode == CFS_MODE_PSGCFS) {
+            skip = fabs(cost_new - cost_old) < 1e-4;        // stop_inner, MAX_I_ITER = 1 (PSGCFS_FANUC.m:136-142)
+            if (!skip) {
+                cost_old = cost_new;                        // PSGCFS_FANUC.m:89
+                const double sc = (double)iter_O * (double)iter_O + 1.0;
+                const bool have = P.noise != nullptr && noise_row < P.noise_rows;
+                for (int k = tid; k < HN; k += FT) {
+                    const double nz = have ? P.noise[((size_t)b * P.noise_rows + noise_row) * nn + k] : 0.0;
+                    xs[k] = s_u[k] - P.alpha * ((s_qu[k] + P.ff[(size_t)b * nn + k]) + 10.0 * nz / sc);   // :109
+                }
+                ++noise_row;
+            }
+        } else {
+            cost_old = cost_new;                            // CFS_FANUC.m:67
+            for (int k = tid; k < HN; k += FT) xs[k] = P.x0[(size_t)b * nn + k];
+        }
+        int qp_status = QP_OK, iters = 0;
+        int qhi = 0, nfree = 0;                             // slots in use: [0,qhi) minus the free stack
+        if (!skip) {
+            // rhs = (d - margin) - Diff'*Bj(1:nj,:)*u   (CFS_FANUC.m:119-120), with Bpos*u from a rollout of u
+            for (int k = tid; k < HN; k += FT) wb[k] = s_u[k];
+            for (int e = tid; e < ncon; e += FT) s_flag[e] = 0;
+            Pr.zero(s_pt, tid, 0);
+            if (tid < QB) { s_d[tid] = 0.0; s_r[tid] = 0.0; s_rho[tid] = 0.0; s_prow[tid] = 0.0; s_lam[tid] = 0.0; s_act[tid] = -1; }
+            __syncthreads();
+            roll_lds<NJ>(wb, H, dt, tid);
+            roll_lds<NJ>(xs, H, dt, tid);
+            __syncthreads();
+            for (int e = tid; e < nobs * H; e += FT) {
+                const int j = e / H, i = e - j * H;
+                double gp = 0.0;
+#pragma unroll
+                for (int c = 0; c < NJ; ++c) gp += s_g[e * NJ + c] * wb[2 * HN + i * NJ + c];
+                s_rhs[e] = (s_rhs[e] - s_margin[j]) - gp;
+            }
+            __syncthreads();
+            // Rigorous early infeasibility test.  At step 1 the iterate minimises the objective over a
+            // subset of the constraints, so its objective value never exceeds the optimum, which in turn
+            // is at most max{f(v): v in the box} <= f(x0) + lambda_max/2 (R + |x0|)^2, the box being
+            // +-MAX_input (CFS) or what the velocity limits allow per step (PSGCFS).  A diverging dual
+            // iterate (infeasible QP) crosses that bound long before fp64 loses the plot.
+            double fgain = 0.0, fbound;
+            {
+                double p0 = 0.0, p1 = 0.0;
+                for (int k = tid; k < HN; k += FT) {
+                    const int c = k % NJ;
+                    const double rb_ = P.has_bounds ? s_mx[k] : (2.0 * s_lim[c] + fabs(s_v0[c])) / dt;
+                    p0 += rb_ * rb_;
+                    p1 += xs[k] * xs[k];
+                }
+                p0 = block_sum(p0, red, tid);
+                p1 = block_sum(p1, red, tid);
+                const double lmax = P.mode == CFS_MODE_CFS ? 1.0 / P.alpha : 1.0;
+                const double rr_ = sqrt(p0) + sqrt(p1);
+                fbound = 1.0001 * 0.5 * lmax * rr_ * rr_;
+            }
+
+            for (;;) {
+                if (fgain > fbound) { qp_status = QP_INFEASIBLE; break; }
+                // step 1: most violated constraint (constraints are strided over the threads)
+                double sbest = 0.0;
+                int cbest = 0x7fffffff;
+                for (int e = tid; e < ncon; e += FT) {
+                    if (s_flag[e]) continue;
+                    int code;
+                    if (e < nobs * H) { const int j = e / H; code = mk_code(CT_COL, e - j * H, j); }
+                    else {
+                        const int f = e - nobs * H, ty = f / HN, k = f - ty * HN, i = k / NJ;
+                        code = mk_code(1 + ty, i, k - i * NJ);
+                    }
+                    double bb;
+                    const double sl = slack_of<NJ>(code, xs, s_g, s_rhs, s_lim, s_v0, s_mx, H, &bb);
+                    if (sl < -1e-11 * (1.0 + fabs(bb)) && sl < sbest) { sbest = sl; cbest = code; }
+                }
+                block_argmin(sbest, cbest, red, tid);
+                if (cbest == 0x7fffffff) break;              // primal feasible: optimum
+                const int pc = cbest, ptype = pc >> 16, pi = (pc >> 8) & 0xff, pj = pc & 0xff;
+                const int pidx = ptype == CT_COL ? pj * H + pi : nobs * H + (ptype - 1) * HN + pi * NJ + pj;
+                double sp = sbest, lam_p = 0.0;
+
+                // step 2
+                for (;;) {
+                    if (++iters > maxit) { qp_status = QP_NUMERIC; break; }
+                    // w = H^{-1} n_p (gather of <= NJ family columns), its rollout, d = N'w
+                    for (int k = tid; k < HN; k += FT) {
+                        double w;
+                        if (ptype == CT_COL) {
+                            w = 0.0;
+#pragma unroll
+                            for (int cs = 0; cs < NJ; ++cs) w += s_g[(pj * H + pi) * NJ + cs] * P.M1[(size_t)(pi * NJ + cs) * nn + k];
+                        } else {
+                            const double *Mx = (ptype == CT_VELP || ptype == CT_VELM) ? P.M2 : P.M3;
+                            const double sg = (ptype == CT_VELP || ptype == CT_BNDP) ? -1.0 : 1.0;
+                            w = sg * Mx[(size_t)(pi * NJ + pj) * nn + k];
+                        }
+                        wb[k] = w;
+                    }
+                    __syncthreads();
+                    roll_lds<NJ>(wb, H, dt, tid);
+                    __syncthreads();
+                    const double spp = ndot<NJ>(pc, wb, s_g, H);
+                    const int myact = tid < qhi ? s_act[tid] : -1;
+                    if (tid < qhi) s_d[tid] = myact >= 0 ? ndot<NJ>(myact, wb, s_g, H) : 0.0;
+                    __syncthreads();
+                    // r = P d
+                    if (tid < qhi) s_r[tid] = myact >= 0 ? Pr.dot(s_d, s_pt, tid, qhi) : 0.0;
+                    __syncthreads();
+                    // z = w - Y'r, rollout, then iterative refinement against the true Gram matrix
+                    double delta = 0.0;
+                    for (int pass = 0; pass < 4; ++pass) {
+                        const double *coef = pass == 0 ? s_r : s_rho;      // pass>0: correction dr held in s_rho
+                        const int qa = min(qhi, QY);
+                        for (int k = tid; k < HN; k += FT) {
+                            double z = pass == 0 ? wb[k] : zb[k];
+                            for (int a = 0; a < qa; ++a) z -= coef[a] * s_Y[a * HN + k];
+                            for (int a = qa; a < qhi; ++a) z -= coef[a] * Yg[(size_t)a * nn + k];
+                            zb[k] = z;
+                        }
+                        __syncthreads();
+                        roll_lds<NJ>(zb, H, dt, tid);
+                        __syncthreads();
+                        delta = ndot<NJ>(pc, zb, s_g, H);              // n_p'z
+                        if (qhi == nfree || pass == 3) break;
+                        // residual rho_a = n_a'z (zero in exact arithmetic)
+                        if (tid < qhi) s_prow[tid] = myact >= 0 ? ndot<NJ>(myact, zb, s_g, H) : 0.0;
+                        __syncthreads();
+                        double rr = 0.0, rmax = 0.0, dmax = 0.0;
+                        for (int a = 0; a < qhi; ++a) {
+                            const double ra = s_prow[a];
+                            rr += s_r[a] * ra;
+                            rmax = fmax(rmax, fabs(ra));
+                            dmax = fmax(dmax, fabs(s_d[a]));
+                        }
+                        const double ref = fmax(fabs(delta), DEP_TOL_F * spp);
+                        if (!(fabs(rr) > 1e-4 * ref || rmax > 1e-9 * (dmax + 1e-300))) break;
+                        __syncthreads();                               // s_r / s_rho are about to change
+                        if (tid < qhi) {                                // dr = P rho ; r += dr
+                            const double dr = myact >= 0 ? Pr.dot(s_prow, s_pt, tid, qhi) : 0.0;
+                            s_rho[tid] = dr;
+                            s_r[tid] += dr;
+                        }
+                        __syncthreads();
+                    }
+                    const bool dependent = !(delta > DEP_TOL_F * spp);
+                    // step lengths
+                    double t1 = INFINITY;
+                    int l = 0x7fffffff;
+                    if (tid < qhi && myact >= 0) {
+                        const double ra = s_r[tid];
+                        if (ra > 0.0) { t1 = s_lam[tid] / ra; l = tid; }
+                    }
+                    block_argmin(t1, l, red, tid);
+                    const double t2 = dependent ? INFINITY : -sp / delta;
+                    const double t = fmin(t1, t2);
+                    if (P.dbg && b == P.dbg_b && tid == 0) {
+                        const int n = (int)P.dbg[0];
+                        if (n < P.dbg_cap) {
+                            double *o = P.dbg + 8 + (size_t)n * 8;
+                            o[0] = iter_O * 100000.0 + iters; o[1] = qhi - nfree; o[2] = pidx; o[3] = sp;
+                            o[4] = delta / spp; o[5] = t1; o[6] = t2; o[7] = l;
+                            P.dbg[0] = n + 1;
+                        }
+                    }
+                    if (!(t < INFINITY)) { qp_status = QP_INFEASIBLE; break; }
+                    const bool full = !dependent && t2 <= t1;
+                    if (!dependent) {
+                        for (int k = tid; k < 3 * HN; k += FT) xs[k] += t * zb[k];
+                        fgain += t * delta * (0.5 * t + lam_p);          // Goldfarb-Idnani step (c)(ii)
+                    }
+                    if (tid < qhi && myact >= 0) s_lam[tid] -= t * s_r[tid];
+                    lam_p += t;
+                    if (full) {
+                        // P <- [P + r r'/delta, -r/delta; -r'/delta, 1/delta] in a free slot: with r[slot] := -1
+                        // the bordered update is one axpy per old row and one scaled copy for the new row
+                        int slot;
+                        if (nfree > 0) slot = s_free[nfree - 1];
+                        else slot = qhi;
+                        if (slot >= QB || qhi - nfree >= nn) { qp_status = QP_NUMERIC; break; }
+                        const int qn = max(qhi, slot + 1);
+                        const double inv = 1.0 / delta;
+                        __syncthreads();
+                        if (tid == 0) s_r[slot] = -1.0;
+                        if (slot >= PR && slot == qhi && tid < QB) s_pt[(slot - PR) * QB + tid] = 0.0;   // fresh tail column
+                        __syncthreads();
+                        if (tid < qhi && myact >= 0) Pr.axpy(s_r[tid] * inv, s_r, s_pt, tid, qn);
+                        else if (tid == slot) Pr.set_scaled(-inv, s_r, s_pt, tid, qn);
+                        if (slot < QY) { for (int k = tid; k < HN; k += FT) s_Y[slot * HN + k] = wb[k]; }
+                        else { for (int k = tid; k < HN; k += FT) Yg[(size_t)slot * nn + k] = wb[k]; }
+                        if (tid == 0) { s_act[slot] = pc; s_lam[slot] = lam_p; s_flag[pidx] = 1; }
+                        if (nfree > 0) --nfree;
+                        qhi = qn;
+                        __syncthreads();
+                        break;                                          // back to step 1
+                    }
+                    // partial step: drop blocking constraint l: rank-1 downdate (which also annihilates
+                    // column l up to rounding), zero row l, push the slot on the free stack
+                    {
+                        const int gone = s_act[l];
+                        __syncthreads();
+                        if (tid == l) Pr.store(s_prow, s_pt, tid, qhi);
+                        if (tid < QB) s_rho[tid] = tid == l ? 0.0 : 1.0;     // exact column mask
+                        __syncthreads();
+                        const double pll = s_prow[l];
+                        if (tid < qhi && myact >= 0 && tid != l) Pr.axpy_mask(-(s_prow[tid] / pll), s_prow, s_rho, s_pt, tid, qhi);
+                        if (tid == l) Pr.zero(s_pt, tid, qhi);
+                        if (tid == 0) {
+                            s_act[l] = -1;
+                            s_lam[l] = 0.0;
+                            s_free[nfree] = l;
+                            const int gt = gone >> 16, gi = (gone >> 8) & 0xff, gj = gone & 0xff;
+                            s_flag[gt == CT_COL ? gj * H + gi : nobs * H + (gt - 1) * HN + gi * NJ + gj] = 0;
+                        }
+                        ++nfree;
+                        __syncthreads();
+                    }
+                    { double bb; sp = slack_of<NJ>(pc, xs, s_g, s_rhs, s_lim, s_v0, s_mx, H, &bb); }
+                }
+                if (qp_status != QP_OK) break;
+            }
+        }
+        total_iter += iters;
+        if (qp_status != QP_OK) {        // the reference would crash here (CFS_FANUC.m:92); report instead
+            status = qp_status == QP_INFEASIBLE ? CFS_QP_INFEASIBLE : CFS_NUMERIC;
+            break;
+        }
+
+        // =========================================================================================
+        // new u, rollout (CFS_FANUC.m:86-95), get_cost, store_result, iter_O++, stop_outer
+        // =========================================================================================
+        if (skip) {
+            for (int k = tid; k < HN; k += FT) xs[k] = s_u[k];
+            __syncthreads();
+            roll_lds<NJ>(xs, H, dt, tid);
+            __syncthreads();
+        }
+        double du2 = 0.0, dx2 = 0.0;
+        for (int k = tid; k < HN; k += FT) {
+            const int i = k / NJ, c = k - i * NJ;
+            const double un = xs[k], e = s_u[k] - un;
+            du2 += e * e;
+            const double th = (s_th0[c] + ((double)(i + 1) * dt) * s_v0[c]) + xs[2 * HN + k];
+            const double om = s_v0[c] + xs[HN + k];
+            const double oth = P.mode == CFS_MODE_PSGCFS ? 1.0 : s_x[i * NS + c];          // EVAL.m:47, SURVEY N1
+            const double oom = P.mode == CFS_MODE_PSGCFS ? 1.0 : s_x[i * NS + NJ + c];
+            dx2 += (th - oth) * (th - oth) + (om - oom) * (om - oom);
+            s_x[i * NS + c] = th;
+            s_x[i * NS + NJ + c] = om;
+        }
+        du2 = block_sum(du2, red, tid);
+        dx2 = block_sum(dx2, red, tid);
+        for (int k = tid; k < HN; k += FT) s_u[k] = xs[k];
+        __syncthreads();
+        // cost = 0.5*u'*QQ*u + ff'*u + caug (EVAL.m:52); QQ*u also feeds the next PSG step
+        double cpart = 0.0;
+        for (int k = tid; k < HN; k += FT) {
+            double s = 0.0;
+            for (int c = 0; c < HN; ++c) s += P.QQ[k + (size_t)c * nn] * s_u[c];
+            s_qu[k] = s;
+            cpart += s_u[k] * (0.5 * s + P.ff[(size_t)b * nn + k]);
+        }
+        const double cost = block_sum(cpart, red, tid) + P.caug[b];
+        if (tid == 0) {
+            const size_t o = (size_t)b * P.max_o_iter + (iter_O - 1);
+            P.cost_all[o] = cost;                              // EVAL.m:56-58
+            P.e_cost_all[o] = fabs(cost_old - cost);
+            P.e_u_all[o] = sqrt(du2);
+        }
+        cost_new = cost;
+        ++iter_O;                                              // CFS_FANUC.m:77
+        if (sqrt(dx2) < P.epsilon_O) { done = true; status = CFS_OK_CONVERGED; }     // EVAL.m:64-68
+        else if (iter_O > P.max_o_iter) { done = true; status = CFS_OK_MAXITER; }    // EVAL.m:69-72
+    }
+
+    // ---- results -----------------------------------------------------------------------------------
+    __syncthreads();
+    for (int e = tid; e < HN; e += FT) P.u[(size_t)b * nn + e] = s_u[e];
+    for (int e = tid; e < NX; e += FT) P.x_[(size_t)b * NX + e] = s_x[e];
+    if (tid == 0) { P.iter_O[b] = iter_O; P.total_iter[b] = total_iter; P.status[b] = status; }
+}
+
+template <int NJ, int QB>
+hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
+{
+    static bool attr_set = false;
+    auto kern = cfs_solve_fused_kernel<NJ, QB>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.B), dim3(FT), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// host: choose the capacities, fill qy / lin_w, launch
+hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
+{
+    const int nn = p.H * nj;
+    const int QB = nn <= 96 ? 96 : 160;
+    const FusedLayout L = fused_layout(nj, p.H, p.nobs, QB, QB < 96 ? QB : 96);
+    const size_t avail = (160 * 1024) / 8 - 64;             // doubles per workgroup, small safety margin
+    if ((size_t)L.total_fixed + 4 * nn > avail) return hipErrorInvalidValue;
+    const size_t region = avail - L.total_fixed;
+    int qy = (int)(region / nn);
+    if (qy > nn) qy = nn;
+    const int NVT = nvt(nj);
+    const size_t per_wp = (size_t)nj * 7 + (size_t)NVT * (18 + p.nobs);
+    int w = (int)(region / per_wp);
+    if (w > p.H) w = p.H;
+    if (w < 1) return hipErrorInvalidValue;
+    p.qy = qy;
+    p.lin_w = w;
+    const size_t need = (size_t)L.total_fixed + std::max((size_t)qy * nn, (size_t)w * per_wp);
+    const size_t lds = need * 8;
+    switch (nj * 1000 + QB) {
+    case 2096: return launch_fused_inst<2, 96>(p, lds, s);
+    case 3096: return launch_fused_inst<3, 96>(p, lds, s);
+    case 4096: return launch_fused_inst<4, 96>(p, lds, s);
+    case 5096: return launch_fused_inst<5, 96>(p, lds, s);
+    case 4160: return launch_fused_inst<4, 160>(p, lds, s);
+    case 5160: return launch_fused_inst<5, 160>(p, lds, s);
+    case 6160: return launch_fused_inst<6, 160>(p, lds, s);
+    case 3160: return launch_fused_inst<3, 160>(p, lds, s);
+    default: return hipErrorInvalidValue;
+    }
+}

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int QP_QL = 16;        // active-set capacity of the LDS instantiation
 constexpr int QP_MAXIT = 6000;   // cap on active-set steps per QP
-constexpr double DEP_TOL = 1e-11;
+constexpr double DEP_TOL = 1e-8;
 
 enum { CT_COL = 0, CT_VELP = 1, CT_VELM = 2, CT_BNDP = 3, CT_BNDM = 4 };
 __device__ __forceinline__ int mk_code(int type, int i, int jc) { return (type << 16) | (i << 8) | jc; }

@@ -1,0 +1,95 @@
+"""Synthetic problem batches of the BASELINE configs (inputs only -- no solver code here).
+
+``config3`` is the headline workload: M200i, 5 joints,
+H=30, cost matrices exactly as main_FANUC.m:64-127, B problems that differ in start, goal and
+8 vertical line-segment obstacles, D=0.2, epsilon=0.25, plus explicit PSGCFS noise.
+
+The obstacle rejection test (axis distance < 0.25 m to the start or goal pose) needs the arm
+distance function.  It is injected as ``dist_fn(robot, theta (N,5), obs (M,6)) -> (N,M)`` so that
+bench.py passes the GPU entry point (``motionplanning_5d_m_amd.dist_arm``) and CPU-only tests pass
+the oracle's; this module itself computes no distances.
+
+Random draws, in this order, from ``numpy.random.default_rng(seed)``:
+  start  = x0c + U(-0.1,0.1)^(B,5);  goal = mirror_joint1(x0c) + U(-0.1,0.1)^(B,5)
+  NC=48 obstacle candidates per problem: radius U(0.35,0.75)^(B,NC), bearing U(0,2pi)^(B,NC),
+  top z U(0.6,1.5)^(B,NC); the first `nobs` candidates that pass the rejection test are kept
+  noise  = 0.1 * standard_normal((B, 20, nn))
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+
+from .robotproperty2 import robotproperty2
+from .sysinfo import FANUC_Qp, FANUC_Rblk, RRT_Qv, build_sys_info, cost_terms
+
+X0C = np.array([0.7825, 0.0284, 0.2172, 0.1444, -1.1779])  # main_FANUC.m:30
+NCAND = 48
+
+
+def _family(H, Qv, cR):
+    robot = robotproperty2("M200i")
+    xg = X0C * np.array([-1.0, 1, 1, 1, 1])  # main_FANUC.m:31
+    x_init = np.zeros(H * 10)
+    return build_sys_info(robot, 5, H, X0C, xg, x_init, Qp=FANUC_Qp, Qv=Qv, Rblk=FANUC_Rblk, cR=cR, lim=np.ones(5),
+                          max_input_blk=np.array([1, 1, np.pi, np.pi, np.pi]) * robot.delta_t, epsilon_O=1e-1,
+                          MAX_O_ITER=20)
+
+
+def _batch_terms(s, x0, xg):
+    """x_init (line reference), xR1, ff, caug for B (start, goal) pairs, vectorised."""
+    B, nj, H = x0.shape[0], s.njoint, s.H
+    th = np.linspace(x0, xg, H + 1)[1:].transpose(1, 0, 2)  # main_FANUC.m:38-49, waypoint 0 dropped
+    x_init = np.concatenate([th, np.zeros_like(th)], axis=2).reshape(B, -1)
+    xR1 = np.concatenate([x0, np.zeros((B, nj))], axis=1)
+    ff = np.zeros((B, H * nj))
+    caug = np.zeros(B)
+    for b in range(B):
+        ff[b], caug[b] = cost_terms(s.Aaug, s.Baug, s.Qaug_state, xR1[b], xg[b], H, nj)
+    return x_init, xR1, ff, caug
+
+
+def config3(dist_fn, B=1024, nobs=8, seed=20260101, H=30):
+    """BASELINE config 3: returns (sys_info family, batch namespace)."""
+    s = _family(H, FANUC_Qp, 50.0)
+    robot = s.robot
+    rng = np.random.default_rng(seed)
+    x0 = X0C + rng.uniform(-0.1, 0.1, (B, 5))
+    xg = X0C * np.array([-1.0, 1, 1, 1, 1]) + rng.uniform(-0.1, 0.1, (B, 5))
+    rad = rng.uniform(0.35, 0.75, (B, NCAND))
+    ang = rng.uniform(0.0, 2 * np.pi, (B, NCAND))
+    z2 = rng.uniform(0.6, 1.5, (B, NCAND))
+    noise = 0.1 * rng.standard_normal((B, 20, H * 5))
+    cx = robot.base[0] + rad * np.cos(ang)
+    cy = robot.base[1] + rad * np.sin(ang)
+    cand = np.stack([cx, cy, np.full_like(cx, 0.001), cx, cy, z2], axis=2)  # (B, NC, 6)
+    obs = np.zeros((B, nobs, 6))
+    for b in range(B):
+        d = np.asarray(dist_fn(robot, np.stack([x0[b], xg[b]]), cand[b]))  # (2, NC)
+        ok = np.nonzero((d >= 0.25).all(axis=0))[0]
+        if ok.size < nobs:
+            raise RuntimeError(f"problem {b}: only {ok.size} of {NCAND} obstacle candidates accepted")
+        obs[b] = cand[b, ok[:nobs]]
+    x_init, xR1, ff, caug = _batch_terms(s, x0, xg)
+    batch = SimpleNamespace(B=B, nobs=nobs, x0=x0, xg=xg, x_init=x_init, xR1=xR1, ff=ff, caug=caug, obs=obs,
+                            noise=noise, margin_cfs=np.full(nobs, 0.25), margin_psg=np.full(nobs, 0.2))
+    return s, batch
+
+
+def config4(B=4096, seed=20260104, H=40):
+    """BASELINE config 4 (synthetic form): B (start, goal) pairs drawn from the RRT
+    sampling region (RRTstar_CFS.m:53), straight-line initial trajectory, the two obstacles and the
+    cost matrices of RRTstar_CFS.m:40-50,124-187."""
+    s = _family(H, RRT_Qv, 10.0)
+    rng = np.random.default_rng(seed)
+    region_s = np.array([np.pi / 2, np.pi / 2, np.pi / 2, np.pi / 1.5, np.pi / 1.5])
+    x0c = np.array([0.421, 0, -0.0092, -0.0010, -1.5786])  # RRTstar_CFS.m:29
+    x0 = x0c + 0.05 * (rng.uniform(-1, 1, (B, 5)) * region_s)
+    xg = np.array([-1.4090, 0.8873, 0.4008, 0.0, 0.4430]) + 0.05 * (rng.uniform(-1, 1, (B, 5)) * region_s)
+    one = np.array([[3.606, 8.413, 0.001, 3.606, 8.413, 1.038], [3.406, 7.813, 0.800, 3.406, 7.813, 1.538]])
+    obs = np.broadcast_to(one, (B, 2, 6)).copy()
+    x_init, xR1, ff, caug = _batch_terms(s, x0, xg)
+    batch = SimpleNamespace(B=B, nobs=2, x0=x0, xg=xg, x_init=x_init, xR1=xR1, ff=ff, caug=caug, obs=obs, noise=None,
+                            margin_cfs=np.full(2, 0.2), margin_psg=np.full(2, 0.2))
+    return s, batch

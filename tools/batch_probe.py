@@ -1,0 +1,43 @@
+"""Developer probe: config-3 batch on the GPU vs the oracle batch, plus a first timing."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import motionplanning_5d_m_amd as pkg
+from motionplanning_5d_m_amd import workloads
+from oracle import oracle as O
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+check = (sys.argv[2] != "nocheck") if len(sys.argv) > 2 else True
+t = time.time()
+s, bt = workloads.config3(lambda rb, th, ob: pkg.dist_arm(rb, th, ob)[0], B=B)
+print(f"workload gen {time.time()-t:.2f}s")
+dev = torch.device("cuda:0")
+for mode in ("CFS", "PSGCFS"):
+    margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
+    slv = pkg.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=B)
+    tt = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    args = [tt(bt.x_init), tt(bt.xR1), tt(bt.ff), tt(bt.caug), tt(bt.obs)]
+    nz = tt(bt.noise) if mode == "PSGCFS" else None
+    out = slv.alloc_outputs(B, dev)
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.time()
+        slv.solve_device(*args, noise=nz, out=out)
+        torch.cuda.synchronize(); dt = time.time() - t0
+        its = int((out.iter_O - 1).sum().item())
+        print(f"[{mode}] rep{rep}: {dt*1e3:.2f} ms, iterations {its}, {its/dt:.3e} it/s, status {np.bincount(out.status.cpu().numpy(), minlength=4)}")
+    if check:
+        t0 = time.time()
+        w = O.optimizer_batch(O.robotproperty2("M200i"), mode, s.H, 5, bt.x_init, bt.xR1, s.QQ, bt.ff, bt.caug, s.Aaug, s.Baug,
+                              s.lim, s.MAX_input, bt.obs, margin, s.epsilon_O, s.MAX_O_ITER, s.alpha,
+                              noise=bt.noise if mode == "PSGCFS" else None, nthreads=0)
+        print(f"[{mode}] oracle batch {time.time()-t0:.1f}s on {O.max_threads()} threads, iterations {int((w.iter_O-1).sum())}")
+        st = out.status.cpu().numpy(); it = out.iter_O.cpu().numpy(); x = out.x_.cpu().numpy(); u = out.u.cpu().numpy()
+        same = (st == w.status) & (it == w.iter_O)
+        print(f"[{mode}] status/iter agreement {same.sum()}/{B}; mismatches: {[(int(b), int(st[b]), int(w.status[b]), int(it[b]), int(w.iter_O[b])) for b in np.nonzero(~same)[0][:10]]}")
+        ok = same & (st < 2)
+        err = np.abs(x - w.x_).max(axis=1)
+        print(f"[{mode}] linf x_ over agreeing solved problems: max {err[ok].max():.3e}, >1e-5: {(err[ok] > 1e-5).sum()}, >1e-7: {(err[ok] > 1e-7).sum()}")
+        bad = same & (st >= 2)
+        if bad.any(): print(f"[{mode}] linf x_ over agreeing failed problems: {np.abs(x - w.x_).max(axis=1)[bad].max():.3e}")
+        worst = np.argsort(-np.where(ok, err, 0))[:5]; print("worst", [(int(b), float(err[b]), int(it[b])) for b in worst])
+    slv.close()
