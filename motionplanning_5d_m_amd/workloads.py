@@ -77,19 +77,25 @@ def config3(dist_fn, B=1024, nobs=8, seed=20260101, H=30):
     return s, batch
 
 
-def config4(B=4096, seed=20260104, H=40):
-    """BASELINE config 4 (synthetic form): B (start, goal) pairs drawn from the RRT
-    sampling region (RRTstar_CFS.m:53), straight-line initial trajectory, the two obstacles and the
-    cost matrices of RRTstar_CFS.m:40-50,124-187."""
+def config4(route_wp, B=4096, seed=20260104, H=40, sigma=0.02):
+    """BASELINE config 4 in synthetic form: the reference runs ONE CFS solve on one
+    RRT route (RRTstar_CFS.m:94-195); the batch here is B perturbed copies of a feasible RRT route
+    (`route_wp`, 5 x nwp, e.g. the matrix of data/200i_xori.mat): every waypoint is jittered by
+    N(0, sigma^2) rad, resampled to H+1 points with zero waypoint velocities (RRTstar_CFS.m:96-100), and
+    solved with the two obstacles and the cost matrices of RRTstar_CFS.m:40-50,124-187."""
+    from .sysinfo import cubic_resample
     s = _family(H, RRT_Qv, 10.0)
     rng = np.random.default_rng(seed)
-    region_s = np.array([np.pi / 2, np.pi / 2, np.pi / 2, np.pi / 1.5, np.pi / 1.5])
-    x0c = np.array([0.421, 0, -0.0092, -0.0010, -1.5786])  # RRTstar_CFS.m:29
-    x0 = x0c + 0.05 * (rng.uniform(-1, 1, (B, 5)) * region_s)
-    xg = np.array([-1.4090, 0.8873, 0.4008, 0.0, 0.4430]) + 0.05 * (rng.uniform(-1, 1, (B, 5)) * region_s)
+    route_wp = np.asarray(route_wp, float)
+    routes = route_wp[None] + sigma * rng.standard_normal((B,) + route_wp.shape)
+    x0, xg = routes[:, :, 0].copy(), routes[:, :, -1].copy()
     one = np.array([[3.606, 8.413, 0.001, 3.606, 8.413, 1.038], [3.406, 7.813, 0.800, 3.406, 7.813, 1.538]])
     obs = np.broadcast_to(one, (B, 2, 6)).copy()
-    x_init, xR1, ff, caug = _batch_terms(s, x0, xg)
+    _, xR1, ff, caug = _batch_terms(s, x0, xg)
+    x_init = np.zeros((B, H * 10))
+    for b in range(B):
+        smp = cubic_resample(routes[b], s.robot.delta_t, H)
+        x_init[b] = np.concatenate([smp[:, 1:].T, np.zeros((H, 5))], axis=1).reshape(-1)
     batch = SimpleNamespace(B=B, nobs=2, x0=x0, xg=xg, x_init=x_init, xR1=xR1, ff=ff, caug=caug, obs=obs, noise=None,
                             margin_cfs=np.full(2, 0.2), margin_psg=np.full(2, 0.2))
     return s, batch

@@ -1,0 +1,62 @@
+"""The multi-GPU path (shard the batch, solve locally, one all_gather) rehearsed with gloo on CPU,
+world size 2.  The local "solve" is replaced by a deterministic function of the problem inputs so
+that the sharding and the collective are what is under test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from motionplanning_5d_m_amd import parallel
+
+
+def test_shard_bounds_cover_the_batch():
+    for B in (1, 2, 7, 1024, 4096):
+        for world in (1, 2, 3, 4, 8):
+            spans = [parallel.shard_bounds(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_best_of():
+    cost = torch.tensor([5.0, 1.0, 3.0, 0.5])
+    assert parallel.best_of(cost, torch.tensor([0, 2, 1, 3])) == 2
+    assert parallel.best_of(cost, torch.tensor([2, 2, 3, 3])) == -1
+
+
+def _worker(rank, world, B, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(0)
+        x_init = torch.randn(B, 12, generator=gen, dtype=torch.float64)      # same inputs on every rank
+        lo, hi = parallel.shard_bounds(B, rank, world)
+        mine = x_init[lo:hi]
+        local = dict(x_=mine * 2 + 1, cost=mine.sum(dim=1), status=(mine[:, 0] > 0).to(torch.int32),
+                     iter_O=torch.arange(lo, hi, dtype=torch.int32))
+        full = parallel.gather_results(local, B)
+        ok = (torch.equal(full["x_"], x_init * 2 + 1) and torch.equal(full["cost"], x_init.sum(dim=1))
+              and torch.equal(full["status"], (x_init[:, 0] > 0).to(torch.int32))
+              and torch.equal(full["iter_O"], torch.arange(B, dtype=torch.int32)))
+        q.put((rank, bool(ok), parallel.best_of(full["cost"], full["status"])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [8, 7])        # even and ragged shards
+def test_all_gather_of_sharded_results_gloo(B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + B
+    procs = [ctx.Process(target=_worker, args=(r, 2, B, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1] and res[0][2] == res[1][2]

@@ -1,0 +1,180 @@
+"""GPU parity: the HIP path (through the C ABI of libcfs_hip.so) against the CPU oracle and the committed
+fixtures.  fp64 everywhere; tolerances are stated per test (the north-star bar is l_inf < 1e-5 rad).
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_RAD = 1e-7        # waypoint tolerance asserted on the reference's own demo problems (bar: 1e-5)
+
+
+# ---- a1-a4: forward kinematics, segment distance, dist_arm, literal num_jac ------------------------
+def test_dist_arm_all_models(gpu, O, golden):
+    for rid, nj in (("M200i", 5), ("M16iB", 5), ("2L", 2)):
+        robot = gpu.robotproperty2(rid)
+        th, obs = golden[f"geom_{rid}/theta"], golden[f"geom_{rid}/obs"]
+        d, lid, pos = gpu.dist_arm(robot, th, obs, want_pos=True)
+        np.testing.assert_allclose(pos, golden[f"geom_{rid}/pos"], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(d, golden[f"geom_{rid}/d"], rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(lid, golden[f"geom_{rid}/linkid"])
+
+
+def test_dist_arm_random_and_edge_cases(gpu, O):
+    rng = np.random.default_rng(11)
+    robot, orobot = gpu.robotproperty2("M200i"), O.robotproperty2("M200i")
+    th = rng.uniform(-2, 2, (257, 5))                           # ragged vs the 256-thread block
+    obs = np.concatenate([rng.uniform([2.8, 8.0, 0, 2.8, 8.0, 0], [3.6, 9.0, 1.5, 3.6, 9.0, 1.5], (5, 6)),
+                          [[3.3, 8.6, 0.4, 3.3, 8.6, 0.4]]])     # + a point obstacle (distLinSeg D2 == 0)
+    d, lid = gpu.dist_arm(robot, th, obs)
+    for n in range(0, 257, 8):
+        for j in range(6):
+            dd, ll = O.dist_arm(orobot, th[n], np.stack([obs[j, :3], obs[j, 3:]], axis=1))
+            assert abs(d[n, j] - dd) < 1e-13 and lid[n, j] == ll
+    # near-zero surrogate branch (dist_arm_2L.m:15-17): obstacle point on link 1
+    r2 = gpu.robotproperty2("2L")
+    d2, l2 = gpu.dist_arm(r2, np.zeros((1, 2)), np.array([[0.15, 0, 0, 0.15, 0, 0]]))
+    assert l2[0, 0] == 1 and abs(d2[0, 0] + 0.15) < 1e-15
+    # empty input is a no-op
+    d0, _ = gpu.dist_arm(robot, np.zeros((0, 5)), obs)
+    assert d0.shape == (0, 6)
+
+
+@pytest.mark.parametrize("name", ["main_FANUC_CFS", "main_2L_CFS", "RRTstar_CFS"])
+def test_linearize_and_dense_get_con(gpu, O, golden, route_wp, name):
+    if name == "main_FANUC_CFS":
+        (R, s, obs), P = gpu.main_FANUC_problem(), O.problem_main_FANUC()
+    elif name == "main_2L_CFS":
+        (R, s, obs), P = gpu.main_2L_problem(), O.problem_main_2L()
+    else:
+        (R, s, obs), P = gpu.RRTstar_CFS_problem(route_wp), O.problem_RRTstar_CFS(route_wp)
+    slv = gpu.CFS_FANUC(obs, s, R)
+    dist, lid, grad = slv._batch.linearize(s.x_[None], gpu.obs_to_array(obs)[None])
+    np.testing.assert_allclose(dist[0], golden[name + "/dist1"], rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(lid[0], golden[name + "/linkid1"])
+    # central difference with eps = 1e-5 amplifies 1e-16 distance rounding to ~1e-10 (num_jac.m:15)
+    np.testing.assert_allclose(grad[0], golden[name + "/grad1"], rtol=0, atol=2e-9)
+    slv.get_con()                                               # public self.Ainq / self.binq, reference row order
+    A, b, *_ = O.get_con(P.ROBOT, P.sys_info, P.obs, P.sys_info.x_, np.zeros(s.H * s.nu))
+    assert slv.Ainq.shape == A.shape
+    np.testing.assert_allclose(slv.Ainq, A, rtol=0, atol=5e-9)
+    np.testing.assert_allclose(slv.binq, golden[name + "/binq1"], rtol=0, atol=1e-13)
+    # at a non-zero linearisation point u (exercises the Diff'*Bj*u term of CFS_FANUC.m:120)
+    u = np.sin(np.arange(s.H * s.nu)) * 0.05
+    x_ = O.rollout(s.H, s.njoint, s.robot.delta_t, P.sys_info.xR1, u)
+    A2, b2, *_ = O.get_con(P.ROBOT, P.sys_info, P.obs, x_, u)
+    Ag, bg = slv._batch.get_con(x_[None], u[None], P.sys_info.xR1[None], gpu.obs_to_array(obs)[None])
+    np.testing.assert_allclose(Ag[0], A2, rtol=0, atol=5e-9)
+    np.testing.assert_allclose(bg[0], b2, rtol=0, atol=5e-9)
+
+
+# ---- a6/a7: the QP on given linearisation data -----------------------------------------------------
+def test_qp_entry_point_cfs_and_psgcfs(gpu, O):
+    R, s, obs = gpu.main_FANUC_problem()
+    P = O.problem_main_FANUC()
+    nn = 150
+    A, b, dist, lid, grad = O.get_con(P.ROBOT, P.sys_info, P.obs, s.x_, np.zeros(nn))
+    G = np.vstack([A, np.eye(nn), -np.eye(nn)]); h = np.concatenate([b, s.MAX_input, s.MAX_input])
+    want, lam_o, _, st, _ = O.qp_solve(s.QQ, s.ff, G, h)
+    slv = gpu.CFSBatch(s, 1, [0.25], mode="CFS", max_batch=2)
+    xR1 = P.sys_info.xR1
+    u, lam, it, stg = slv.qp(np.stack([s.ff, s.ff]), np.zeros((2, nn)), np.stack([xR1, xR1]), np.stack([dist, dist]),
+                             np.stack([grad, grad]))
+    assert st == 0 and (stg == 0).all()
+    np.testing.assert_allclose(u[0], want, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(u[0], u[1])
+    # multipliers: collision rows first, ordered (j, i)
+    lam_col = lam_o[0:330:11]
+    np.testing.assert_allclose(lam[0][:30], lam_col, rtol=1e-6, atol=1e-6)
+    # PSGCFS projection: min |v - u_|^2 s.t. Ainq v <= binq, no bounds (PSGCFS_FANUC.m:117-120)
+    A2, b2, dist2, _, grad2 = O.get_con(P.ROBOT, P.sys_info, P.obs, s.x_, np.zeros(nn), "PSGCFS")
+    u_ = -s.alpha * s.ff
+    want2, _, _, st2, _ = O.qp_solve(np.eye(nn), -u_, A2, b2)
+    slv2 = gpu.CFSBatch(s, 1, [0.2], mode="PSGCFS", max_batch=1)
+    u2, _, _, st3 = slv2.qp(u_[None], np.zeros((1, nn)), xR1[None], dist2[None], grad2[None])
+    assert st2 == 0 and st3[0] == 0
+    np.testing.assert_allclose(u2[0], want2, rtol=0, atol=1e-12)
+
+
+# ---- a8/a9: the whole optimizer() on the reference's demo problems -----------------------------------
+def _compare(got, g, name, caug):
+    it, tot, st = g[name + "/iter_status"]
+    assert got.status == st and got.iter_O == it
+    assert np.abs(got.x_ - g[name + "/x_"]).max() < TOL_RAD
+    assert np.abs(got.u - g[name + "/u"]).max() < TOL_RAD
+    np.testing.assert_allclose(got.eval.cost_all, g[name + "/cost_all"], rtol=1e-8)
+    np.testing.assert_allclose(got.eval.e_u_all, g[name + "/e_u_all"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got.eval.e_cost_all, g[name + "/e_cost_all"], rtol=1e-6, atol=1e-4)
+
+
+def test_main_fanuc_cfs(gpu, golden):
+    R, s, obs = gpu.main_FANUC_problem()
+    got = gpu.CFS_FANUC(obs, s, R).optimizer()
+    _compare(got, golden, "main_FANUC_CFS", s.caug)
+    assert got.status == 0 and got.iter_O == 11               # "Converged at step11" 
+    x = got.x_.reshape(30, 10)
+    np.testing.assert_allclose(x[14, :5], [-0.170879, -0.202055, 1.012415, 0.183991, -0.739707], atol=1e-6)
+
+
+def test_main_fanuc_psgcfs(gpu, golden):
+    R, s, obs = gpu.main_FANUC_problem()
+    got = gpu.PSGCFS_FANUC(obs, s, R).optimizer(noise=golden["main_FANUC_PSGCFS/noise"])
+    _compare(got, golden, "main_FANUC_PSGCFS", s.caug)
+    assert got.status == 1 and got.iter_O == 21               # always MAX_O_ITER iterations
+
+
+def test_main_2l_reports_infeasible_at_iteration_2(gpu, golden):
+    R, s, obs = gpu.main_2L_problem()
+    got = gpu.CFS_FANUC(obs, s, R).optimizer()
+    assert got.status == 2 and got.iter_O == 2                 # SURVEY N9; the reference would crash at CFS_FANUC.m:92
+    assert np.abs(got.u - golden["main_2L_CFS/hist_u1"]).max() < TOL_RAD      # iteration-1 quantities are defined
+    assert np.abs(got.x_ - golden["main_2L_CFS/x_"]).max() < TOL_RAD
+    np.testing.assert_allclose(got.eval.cost_all, golden["main_2L_CFS/cost_all"], rtol=1e-9)
+    R, s, obs = gpu.main_2L_problem(lim=(1, 1))                # the converging variant
+    _compare(gpu.CFS_FANUC(obs, s, R).optimizer(), golden, "main_2L_lim1_CFS", s.caug)
+
+
+def test_rrtstar_cfs_stage(gpu, golden, route_wp):
+    R, s, obs = gpu.RRTstar_CFS_problem(route_wp)
+    got = gpu.CFS_FANUC(obs, s, R).optimizer()
+    _compare(got, golden, "RRTstar_CFS", s.caug)
+    assert got.status == 0 and got.iter_O == 18
+
+
+def test_m16ib_model_and_three_obstacles(gpu, O):
+    # M16iB distance function (dist_arm_3D_Heu_2.m) and a 3-obstacle problem (BASELINE config 2 variant)
+    R, s, obs = gpu.main_FANUC_problem()
+    # (a set on which the oracle itself is insensitive to a 1e-10 perturbation of x_init; other triples
+    #  amplify such a perturbation to 4e-4 rad -- see DESIGN.md "Numerical limits")
+    obs3 = obs + [gpu.cylinder((2700, 8900, 1), (2700, 8900, 900), 0.2, 0.25), gpu.cylinder((3150, 7800, 1), (3150, 7800, 700), 0.2, 0.25)]
+    got = gpu.CFS_FANUC(obs3, s, R).optimizer()
+    P = O.problem_main_FANUC()
+    want = O.optimizer(P.ROBOT, P.sys_info, [dict(l=o["l"], D=o["D"], epsilon=o["epsilon"]) for o in obs3], "CFS")
+    assert got.status == want.status and got.iter_O == want.iter_O and np.abs(got.x_ - want.x_).max() < TOL_RAD
+    s16 = copy.copy(s); s16.robot = gpu.robotproperty2("M16iB")
+    th0 = np.array([0.5, 1.2, 0.1, 0.0, -1.2]); th1 = np.array([-0.5, 1.2, 0.1, 0.0, -1.2])
+    s16 = gpu.build_sys_info(s16.robot, 5, 20, th0, th1, gpu.line_reference(th0, th1, 20), Qp=np.diag([10.0, 10, 1, 1, 1]),
+                             Qv=np.diag([10.0, 10, 1, 1, 1]), Rblk=np.eye(5) * 2, cR=50.0, lim=np.ones(5), max_input_blk=np.ones(5),
+                             epsilon_O=0.1, MAX_O_ITER=20)
+    ob = [gpu.cylinder((4300, 8500, 1), (4300, 8500, 1500), 0.2, 0.3)]
+    got = gpu.CFS_FANUC(ob, s16, "M16iB").optimizer()
+    Ps = copy.copy(P.sys_info); orb = O.robotproperty2("M16iB")
+    t = O.build_sys_info(orb, 5, 20, th0, th1, O.line_reference(th0, th1, 20), Qp=np.diag([10.0, 10, 1, 1, 1]),
+                         Qv=np.diag([10.0, 10, 1, 1, 1]), Rblk=np.eye(5) * 2, cR=50.0, lim=np.ones(5), max_input_blk=np.ones(5),
+                         epsilon_O=0.1, MAX_O_ITER=20)
+    want = O.optimizer("M16iB", t, [dict(l=ob[0]["l"], D=0.2, epsilon=0.3)], "CFS")
+    assert got.status == want.status and got.iter_O == want.iter_O and np.abs(got.x_ - want.x_).max() < TOL_RAD
+
+
+def test_zero_iterations_and_max_iter_edge(gpu):
+    R, s, obs = gpu.main_FANUC_problem()
+    s0 = copy.copy(s); s0.MAX_O_ITER = 0
+    got = gpu.CFS_FANUC(obs, s0, R).optimizer()
+    assert got.status == 1 and got.iter_O == 1 and len(got.eval.cost_all) == 0 and np.array_equal(got.x_, s.x_)
+    s1 = copy.copy(s); s1.MAX_O_ITER = 1
+    got = gpu.CFS_FANUC(obs, s1, R).optimizer()
+    assert got.status == 1 and got.iter_O == 2 and len(got.eval.cost_all) == 1

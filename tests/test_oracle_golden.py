@@ -1,0 +1,71 @@
+"""Oracle against the committed fixtures and against the survey's independent scratch numbers (CPU).
+
+"parity unpinned": the reference has no tests/golden vectors and MATLAB/quadprog cannot run here.
+What pins the oracle: (1) the distLinSeg doc example, (2) KKT certificates + an independent NNLS
+solve (test_oracle_qp.py), (3) the numbers below, which SURVEY.md (N3, N8-N10) obtained with a
+separately written numpy/NNLS restatement -- two independent restatements agree.
+"""
+import numpy as np
+
+
+def _run(O, P, mode="CFS", noise=None):
+    return O.optimizer(P.ROBOT, P.sys_info, P.obs, mode, noise=noise, history=True)
+
+
+def _check(r, g, name):
+    assert [r.iter_O, r.total_iter, r.status] == list(g[name + "/iter_status"])
+    np.testing.assert_allclose(r.x_, g[name + "/x_"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r.u, g[name + "/u"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r.cost_all, g[name + "/cost_all"], rtol=1e-12)
+
+
+def test_main_fanuc_cfs(O, golden):
+    P = O.problem_main_FANUC()
+    r = _run(O, P)
+    _check(r, golden, "main_FANUC_CFS")
+    # SURVEY N3 / N8 (independent restatement): converged at step 11, costs, waypoints
+    assert r.status == 0 and r.iter_O == 11
+    c = r.cost_all - P.sys_info.caug
+    assert abs(c[0] + 122076.00) < 0.01 and abs(c[-1] + 122461.43) < 0.01
+    x = r.x_.reshape(30, 10)
+    np.testing.assert_allclose(x[0, :5], [0.775666, 0.024983, 0.229527, 0.143153, -1.169345], atol=1e-6)
+    np.testing.assert_allclose(x[14, :5], [-0.170879, -0.202055, 1.012415, 0.183991, -0.739707], atol=1e-6)
+    np.testing.assert_allclose(x[29, :5], [-0.782747, 0.028201, 0.218965, 0.145129, -1.177633], atol=1e-6)
+    dx = [np.linalg.norm(r.hist_x[k] - (r.hist_x[k - 1] if k else P.sys_info.x_)) for k in range(10)]
+    np.testing.assert_allclose(dx, [15.98, 5.71, 13.87, 1.42, 0.80, 0.46, 0.30, 0.20, 0.106, 0.070], atol=6e-3)
+    assert r.kkt[0] < 1e-12 and r.kkt[1] < 1e-12 and r.kkt[3] < 1e-9
+
+
+def test_main_fanuc_psgcfs(O, golden):
+    r = _run(O, O.problem_main_FANUC(), "PSGCFS", golden["main_FANUC_PSGCFS/noise"])
+    _check(r, golden, "main_FANUC_PSGCFS")
+    assert r.status == 1 and r.iter_O == 21          # x_old is never refreshed -> always MAX_O_ITER
+
+
+def test_main_2l(O, golden):
+    r = _run(O, O.problem_main_2L())
+    _check(r, golden, "main_2L_CFS")
+    assert r.status == 2 and r.iter_O == 2           # the QP of outer iteration 2 is infeasible
+    P = O.problem_main_2L(lim=(1, 1))
+    r = _run(O, P)
+    _check(r, golden, "main_2L_lim1_CFS")
+    assert r.status == 0 and r.iter_O == 9 and abs((r.cost_all - P.sys_info.caug)[-1] + 123412.5759) < 1e-3
+
+
+def test_rrtstar_cfs(O, golden, route_wp):
+    P = O.problem_RRTstar_CFS(route_wp)
+    r = _run(O, P)
+    _check(r, golden, "RRTstar_CFS")
+    assert r.status == 0 and r.iter_O == 18 and abs((r.cost_all - P.sys_info.caug)[-1] + 73637.01) < 0.01
+
+
+def test_first_iteration_fixtures(O, golden, route_wp):
+    for name, P in (("main_FANUC_CFS", O.problem_main_FANUC()), ("main_2L_CFS", O.problem_main_2L()),
+                    ("RRTstar_CFS", O.problem_RRTstar_CFS(route_wp))):
+        s = P.sys_info
+        A, b, dist, lid, grad = O.get_con(P.ROBOT, s, P.obs, s.x_, np.zeros(s.H * s.nu))
+        np.testing.assert_array_equal(b, golden[name + "/binq1"])
+        np.testing.assert_array_equal(dist, golden[name + "/dist1"])
+        np.testing.assert_array_equal(lid, golden[name + "/linkid1"])
+        np.testing.assert_array_equal(grad, golden[name + "/grad1"])
+        np.testing.assert_allclose([A.sum(), np.abs(A).sum()], golden[name + "/Ainq1_sum"], rtol=1e-13)
