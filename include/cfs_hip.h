@@ -146,6 +146,15 @@ int cfs_solve_batch(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out 
  * in->B <= max_batch.  This is the entry bench.py times (inputs resident in HBM). */
 int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream);
 
+/* ---- measurement ------------------------------------------------------------------------------
+ * When enabled, cfs_solve_batch_device brackets each kernel launch with hipEvents recorded on the
+ * caller's stream (the reference has only tic/toc around the solver calls, main_FANUC.m:140-152).
+ * cfs_profile_read synchronises on those events and returns, accumulated since the last read: the
+ * milliseconds spent in the fused solve kernel and in the MFMA batched product, and the number of
+ * solves. */
+int cfs_profile_enable(cfs_problem *p, int on);
+int cfs_profile_read(cfs_problem *p, double *solve_kernel_ms, double *gemm_kernel_ms, int *solves);
+
 /* ---- pieces of the path (host pointers; for callers that drive the outer loop themselves and
  *      for kernel-level parity tests) ------------------------------------------------------- */
 

@@ -137,8 +137,12 @@ struct cfs_problem {
     DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg, Pt;
     DevBuf<int> qp_status, qp_iter, noise_row, linkid;
     DevBuf<unsigned char> done;
+    bool prof = false;
+    std::vector<hipEvent_t> ev;   // 4 per profiled solve: gemm start/stop, fused start/stop
     void release_all()
     {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
         rb.release(); QQ.release(); Hinv.release(); Hq.release(); M1.release(); M2.release(); M3.release();
         M1n.release(); M2n.release(); Pt.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
@@ -347,11 +351,16 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nj = p->d.njoint, nn = p->nn, nx = p->nx, K = p->d.MAX_O_ITER;
 
+    hipEvent_t e4[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (p->prof)
+        for (int k = 0; k < 4; ++k) HIPCHK(hipEventCreate(&e4[k]));
+    if (p->prof) HIPCHK(hipEventRecord(e4[0], s));
     if (p->d.mode == CFS_MODE_CFS) {     // unconstrained minimiser -H^{-1} ff (MFMA), constant over the outer loop
         GemvParams g;
         g.B = B; g.nn = nn; g.M = p->Hinv.p; g.X = in->ff; g.Y = p->x0.p; g.scale = -1.0;
         launch_batched_gemv(g, s);
     }
+    if (p->prof) { HIPCHK(hipEventRecord(e4[1], s)); HIPCHK(hipEventRecord(e4[2], s)); }
     FusedParams fp;
     memset(&fp, 0, sizeof fp);
     fp.rb = p->rb.p; fp.B = B; fp.H = p->d.H; fp.nobs = p->d.nobs; fp.mode = p->d.mode;
@@ -367,6 +376,10 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
     (void)nx;
     HIPCHK(launch_fused(nj, fp, s));
+    if (p->prof) {
+        HIPCHK(hipEventRecord(e4[3], s));
+        for (int k = 0; k < 4; ++k) p->ev.push_back(e4[k]);
+    }
     HIPCHK(hipGetLastError());
     return CFS_SUCCESS;
 }
@@ -412,6 +425,35 @@ int cfs_solve_batch(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out 
     st.down(out->total_iter, dout.total_iter, B);
     st.down(out->status, dout.status, B);
     if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+int cfs_profile_enable(cfs_problem *p, int on)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    p->prof = on != 0;
+    return CFS_SUCCESS;
+}
+
+int cfs_profile_read(cfs_problem *p, double *solve_kernel_ms, double *gemm_kernel_ms, int *solves)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    HIPCHK(hipSetDevice(p->device));
+    double fused = 0.0, gemm = 0.0;
+    const int n = (int)(p->ev.size() / 4);
+    for (int k = 0; k < n; ++k) {
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(p->ev[4 * k + 3]));
+        HIPCHK(hipEventElapsedTime(&ms, p->ev[4 * k + 0], p->ev[4 * k + 1]));
+        gemm += ms;
+        HIPCHK(hipEventElapsedTime(&ms, p->ev[4 * k + 2], p->ev[4 * k + 3]));
+        fused += ms;
+    }
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    p->ev.clear();
+    if (solve_kernel_ms) *solve_kernel_ms = fused;
+    if (gemm_kernel_ms) *gemm_kernel_ms = gemm;
+    if (solves) *solves = n;
     return CFS_SUCCESS;
 }
 

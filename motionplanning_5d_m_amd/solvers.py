@@ -138,6 +138,17 @@ class CFSBatch:
         _lib.check(self._lib.cfs_solve_batch_device(self._h, C.byref(i), C.byref(o), C.c_void_p(stream)))
         return out
 
+    # ---- measurement ------------------------------------------------------------------------------
+    def profile(self, on=True):
+        _lib.check(self._lib.cfs_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """(ms in the fused solve kernel, ms in the MFMA batched product, solves) since the last read;
+        HIP events on the stream the kernels were launched on."""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        _lib.check(self._lib.cfs_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     # ---- pieces -----------------------------------------------------------------------------------
     def linearize(self, x_, obs):
         x_, obs = _f64(x_), _f64(obs)
