@@ -134,7 +134,7 @@ struct cfs_problem {
     DevBuf<DevRobot> rb;
     DevBuf<double> QQ, Hinv, Hq, M1, M2, M3, M1n, M2n, lim, maxin, margin;
     // workspace (max_batch problems)
-    DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg, Pt;
+    DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg, Pt, u_hist, qu_hist;
     DevBuf<int> qp_status, qp_iter, noise_row, linkid;
     DevBuf<unsigned char> done;
     bool prof = false;
@@ -144,7 +144,7 @@ struct cfs_problem {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         ev.clear();
         rb.release(); QQ.release(); Hinv.release(); Hq.release(); M1.release(); M2.release(); M3.release();
-        M1n.release(); M2n.release(); Pt.release();
+        M1n.release(); M2n.release(); Pt.release(); u_hist.release(); qu_hist.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
         grad.release(); cost_new.release(); cost_old.release(); delta.release(); e_u.release();
         Yg.release(); Tg.release(); qp_status.release(); qp_iter.release(); noise_row.release();
@@ -153,6 +153,8 @@ struct cfs_problem {
 };
 
 // developer aid (not part of the ABI header): trace the active-set steps of one problem of the next solves
+static unsigned long long *g_stamps = nullptr;
+static int g_stamps_B = 0;
 static double *g_dbg = nullptr;
 static int g_dbg_b = -1, g_dbg_cap = 0;
 
@@ -165,6 +167,15 @@ int cfs_debug_trace_begin(int b, int cap)
     if (cap <= 0) return 0;
     if (hipMalloc(reinterpret_cast<void **>(&g_dbg), (size_t)(cap + 1) * 8 * sizeof(double)) != hipSuccess) return -1;
     return hipMemset(g_dbg, 0, (size_t)(cap + 1) * 8 * sizeof(double)) == hipSuccess ? 0 : -1;
+}
+int cfs_debug_stamps(int B, unsigned long long *out)   /* B>0,out==NULL: enable for B problems; out!=NULL: read 12 per problem; B==0: off */
+{
+    if (out) { if (!g_stamps) return -1; if (hipDeviceSynchronize() != hipSuccess) return -1; return hipMemcpy(out, g_stamps, (size_t)g_stamps_B * 12 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+    if (g_stamps) { (void)hipFree(g_stamps); g_stamps = nullptr; }
+    g_stamps_B = B;
+    if (B <= 0) return 0;
+    if (hipMalloc(reinterpret_cast<void **>(&g_stamps), (size_t)B * 12 * 8) != hipSuccess) return -1;
+    return hipMemset(g_stamps, 0, (size_t)B * 12 * 8) == hipSuccess ? 0 : -1;
 }
 int cfs_debug_trace_read(double *out)   /* out: (cap+1)*8 doubles; out[0] = number of records */
 {
@@ -299,6 +310,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     A_(M3, (size_t)nn * nn); A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * 64 * 160); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
     A_(cost_new, Bm); A_(cost_old, Bm); A_(delta, Bm); A_(e_u, Bm); A_(Yg, Bm * nn * nn); A_(Tg, Bm * nn * nn);
+    if (desc->mode == CFS_MODE_CFS) { A_(u_hist, Bm * (size_t)desc->MAX_O_ITER * nn); A_(qu_hist, Bm * (size_t)desc->MAX_O_ITER * nn); }
     A_(qp_status, Bm); A_(qp_iter, Bm); A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H); A_(done, Bm);
 #undef A_
 #define U_(buf, src, count) if (e == hipSuccess) e = hipMemcpy(p->buf.p, src, (count) * sizeof(*p->buf.p), hipMemcpyHostToDevice)
@@ -374,11 +386,24 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     fp.iter_O = out->iter_O; fp.total_iter = out->total_iter; fp.status = out->status;
     fp.Yg = p->Yg.p; fp.Pt = p->Pt.p;
     fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
+    fp.stamps = (g_stamps && B <= g_stamps_B) ? g_stamps : nullptr;
+    fp.u_hist = (p->d.mode == CFS_MODE_CFS && K > 0) ? p->u_hist.p : nullptr;
     (void)nx;
     HIPCHK(launch_fused(nj, fp, s));
     if (p->prof) {
         HIPCHK(hipEventRecord(e4[3], s));
         for (int k = 0; k < 4; ++k) p->ev.push_back(e4[k]);
+    }
+    if (fp.u_hist) {                     // CFS cost history: QQ * (all logged u) on the matrix cores, then the dots
+        if (p->u_hist.n) {
+            GemvParams g;
+            g.B = B * K; g.nn = nn; g.M = p->QQ.p; g.X = p->u_hist.p; g.Y = p->qu_hist.p; g.scale = 1.0;
+            launch_batched_gemv(g, s);
+            CostHistParams ch;
+            ch.B = B; ch.nn = nn; ch.max_o_iter = K; ch.u_hist = p->u_hist.p; ch.qu_hist = p->qu_hist.p;
+            ch.ff = in->ff; ch.caug = in->caug; ch.iter_O = out->iter_O; ch.cost_all = out->cost_all; ch.e_cost_all = out->e_cost_all;
+            launch_cost_history(ch, s);
+        }
     }
     HIPCHK(hipGetLastError());
     return CFS_SUCCESS;

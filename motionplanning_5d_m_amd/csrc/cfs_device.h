@@ -141,8 +141,19 @@ struct FusedParams {
     double *Pt;                  // B x 64 x 160: columns of the inverse Gram matrix beyond the register-resident 96
     double *dbg;                 // optional trace: 8 doubles per active-set step of problem dbg_b (developer aid)
     int dbg_b, dbg_cap;
+    unsigned long long *stamps;  // optional: 16 cycle accumulators per problem (developer aid)
+    double *u_hist;              // CFS: B x max_o_iter x nn log of u per outer iteration (cost history computed afterwards)
 };
 hipError_t launch_fused(int nj, FusedParams p, hipStream_t s);
+
+struct CostHistParams {          // EVAL.get_cost / store_result for a logged u history (CFS mode)
+    int B, nn, max_o_iter;
+    const double *u_hist, *qu_hist;   // B x max_o_iter x nn: u and QQ*u
+    const double *ff, *caug;
+    const int *iter_O;
+    double *cost_all, *e_cost_all;
+};
+void launch_cost_history(const CostHistParams &p, hipStream_t s);
 
 struct InitParams {
     int B, nn, nx, mode, max_o_iter;

@@ -25,6 +25,8 @@
 
 namespace {
 
+#define STAMP(k) do { if (P.stamps) { const unsigned long long t_ = clock64(); acc_[k] += t_ - t0_; t0_ = t_; } } while (0)
+
 constexpr int FT = 256;                  // threads per workgroup
 constexpr double DEP_TOL_F = 1e-8;       // dependent if delta <= tol * n'H^{-1}n: above the eps*cond(H) noise floor of Y = H^{-1}N
 enum { CT_COL = 0, CT_VELP = 1, CT_VELM = 2, CT_BNDP = 3, CT_BNDM = 4 };
@@ -96,22 +98,30 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid)
     return t;
 }
 
-// (Bvel v, Bpos v) of the vector in buf[0..HN) -> buf[HN..2HN), buf[2HN..3HN)   (short prefix sums)
+// inclusive prefix sum over the 64 lanes of a wavefront (DPP row shifts + row broadcasts)
+__device__ __forceinline__ double wave_scan_incl(double v)
+{
+    v += dpp_f64<0x111, 0xf>(0.0, v);   // row_shr:1
+    v += dpp_f64<0x112, 0xf>(0.0, v);   // row_shr:2
+    v += dpp_f64<0x114, 0xf>(0.0, v);   // row_shr:4
+    v += dpp_f64<0x118, 0xf>(0.0, v);   // row_shr:8
+    v += dpp_f64<0x142, 0xa>(0.0, v);   // row_bcast:15 -> rows 1,3
+    v += dpp_f64<0x143, 0xc>(0.0, v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// (Bvel v, Bpos v) of the vector in buf[0..HN) -> buf[HN..2HN), buf[2HN..3HN).  Lane i of a wavefront
+// owns waypoint i (H <= 64); the workgroup's wavefronts share the joints.  Two DPP prefix sums per joint:
+// Bvel v = dt*cumsum(v), Bpos v = dt*cumsum(Bvel v) - dt/2 * Bvel v  (double integrator, robotproperty2.m:136-139).
 template <int NJ>
 __device__ __forceinline__ void roll_lds(double *buf, int H, double dt, int tid)
 {
-    const int HN = H * NJ;
-    for (int k = tid; k < HN; k += FT) {
-        const int i = k / NJ, c = k - i * NJ;
-        double sv = 0.0, sp = 0.0, coef = (double)i + 0.5;
-        for (int ip = 0; ip <= i; ++ip) {
-            const double x = buf[ip * NJ + c];
-            sv += x;
-            sp += coef * x;
-            coef -= 1.0;
-        }
-        buf[HN + k] = dt * sv;
-        buf[2 * HN + k] = (dt * dt) * sp;
+    const int HN = H * NJ, lane = tid & 63, wv = tid >> 6;
+    for (int c = wv; c < NJ; c += FT / 64) {
+        const double x = lane < H ? buf[lane * NJ + c] : 0.0;
+        const double sv = dt * wave_scan_incl(x);
+        const double sp = dt * wave_scan_incl(sv) - (0.5 * dt) * sv;
+        if (lane < H) { buf[HN + lane * NJ + c] = sv; buf[2 * HN + lane * NJ + c] = sp; }
     }
 }
 
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
         if (tid < nobs) s_margin[tid] = P.margin[tid];
     }
     __syncthreads();
+    unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_ = P.stamps ? clock64() : 0ull;
     double cost_new = P.caug[b], cost_old = 100000.0;      // get_cost(zeros) = caug; EVAL.m:29
     int iter_O = 1, total_iter = 0, noise_row = 0, status = CFS_OK_MAXITER;
     bool done = false;
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
         // =========================================================================================
         // the QP of this outer iteration (CFS_FANUC.m:85 | PSGCFS_FANUC.m:106-128)
         // =========================================================================================
+        STAMP(0);                                           // 0: linearisation
         bool skip = false;
         if (P.mode == CFS_MODE_PSGCFS) {
             skip = fabs(cost_new - cost_old) < 1e-4;        // stop_inner, MAX_I_ITER = 1 (PSGCFS_FANUC.m:136-142)
@@ -460,6 +472,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                 fbound = 1.0001 * 0.5 * lmax * rr_ * rr_;
             }
 
+            STAMP(1);                                       // 1: QP setup
             for (;;) {
                 if (fgain > fbound) { qp_status = QP_INFEASIBLE; break; }
                 // step 1: most violated constraint (constraints are strided over the threads)
@@ -478,6 +491,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                     if (sl < -1e-11 * (1.0 + fabs(bb)) && sl < sbest) { sbest = sl; cbest = code; }
                 }
                 block_argmin(sbest, cbest, red, tid);
+                STAMP(2);                                   // 2: step 1 (slack scan + argmin)
                 if (cbest == 0x7fffffff) break;              // primal feasible: optimum
                 const int pc = cbest, ptype = pc >> 16, pi = (pc >> 8) & 0xff, pj = pc & 0xff;
                 const int pidx = ptype == CT_COL ? pj * H + pi : nobs * H + (ptype - 1) * HN + pi * NJ + pj;
@@ -503,6 +517,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                     __syncthreads();
                     roll_lds<NJ>(wb, H, dt, tid);
                     __syncthreads();
+                    STAMP(3);                               // 3: w gather + rollout
                     const double spp = ndot<NJ>(pc, wb, s_g, H);
                     const int myact = tid < qhi ? s_act[tid] : -1;
                     if (tid < qhi) s_d[tid] = myact >= 0 ? ndot<NJ>(myact, wb, s_g, H) : 0.0;
@@ -510,16 +525,30 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                     // r = P d
                     if (tid < qhi) s_r[tid] = myact >= 0 ? Pr.dot(s_d, s_pt, tid, qhi) : 0.0;
                     __syncthreads();
+                    STAMP(4);                               // 4: d = N'w, r = P d
                     // z = w - Y'r, rollout, then iterative refinement against the true Gram matrix
                     double delta = 0.0;
                     for (int pass = 0; pass < 4; ++pass) {
                         const double *coef = pass == 0 ? s_r : s_rho;      // pass>0: correction dr held in s_rho
                         const int qa = min(qhi, QY);
                         for (int k = tid; k < HN; k += FT) {
-                            double z = pass == 0 ? wb[k] : zb[k];
-                            for (int a = 0; a < qa; ++a) z -= coef[a] * s_Y[a * HN + k];
-                            for (int a = qa; a < qhi; ++a) z -= coef[a] * Yg[(size_t)a * nn + k];
-                            zb[k] = z;
+                            double z0 = pass == 0 ? wb[k] : zb[k], z1 = 0.0, z2 = 0.0, z3 = 0.0;
+                            int a = 0;
+                            for (; a + 4 <= qa; a += 4) {               // four independent chains keep the LDS pipe full
+                                z0 -= coef[a] * s_Y[a * HN + k];
+                                z1 -= coef[a + 1] * s_Y[(a + 1) * HN + k];
+                                z2 -= coef[a + 2] * s_Y[(a + 2) * HN + k];
+                                z3 -= coef[a + 3] * s_Y[(a + 3) * HN + k];
+                            }
+                            for (; a < qa; ++a) z0 -= coef[a] * s_Y[a * HN + k];
+                            for (a = qa; a + 4 <= qhi; a += 4) {
+                                z0 -= coef[a] * Yg[(size_t)a * nn + k];
+                                z1 -= coef[a + 1] * Yg[(size_t)(a + 1) * nn + k];
+                                z2 -= coef[a + 2] * Yg[(size_t)(a + 2) * nn + k];
+                                z3 -= coef[a + 3] * Yg[(size_t)(a + 3) * nn + k];
+                            }
+                            for (; a < qhi; ++a) z0 -= coef[a] * Yg[(size_t)a * nn + k];
+                            zb[k] = (z0 + z1) + (z2 + z3);
                         }
                         __syncthreads();
                         roll_lds<NJ>(zb, H, dt, tid);
@@ -527,18 +556,27 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                         delta = ndot<NJ>(pc, zb, s_g, H);              // n_p'z
                         if (qhi == nfree || pass == 3) break;
                         // residual rho_a = n_a'z (zero in exact arithmetic)
-                        if (tid < qhi) s_prow[tid] = myact >= 0 ? ndot<NJ>(myact, zb, s_g, H) : 0.0;
-                        __syncthreads();
                         double rr = 0.0, rmax = 0.0, dmax = 0.0;
-                        for (int a = 0; a < qhi; ++a) {
-                            const double ra = s_prow[a];
-                            rr += s_r[a] * ra;
-                            rmax = fmax(rmax, fabs(ra));
-                            dmax = fmax(dmax, fabs(s_d[a]));
+                        if (tid < qhi) {
+                            const double ra = myact >= 0 ? ndot<NJ>(myact, zb, s_g, H) : 0.0;
+                            s_prow[tid] = ra;
+                            rr = s_r[tid] * ra;
+                            rmax = fabs(ra);
+                            dmax = fabs(s_d[tid]);
                         }
+                        // r'rho, max|rho|, max|d| over the active set: one wave reduction each + one LDS exchange
+                        rr = wave_add(rr);
+                        rmax = -wave_min(-rmax);
+                        dmax = -wave_min(-dmax);
+                        __syncthreads();
+                        if ((tid & 63) == 0) { red[tid >> 6] = rr; red[4 + (tid >> 6)] = rmax; red[8 + (tid >> 6)] = dmax; }
+                        __syncthreads();
+                        rr = (red[0] + red[1]) + (red[2] + red[3]);
+                        rmax = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+                        dmax = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
                         const double ref = fmax(fabs(delta), DEP_TOL_F * spp);
                         if (!(fabs(rr) > 1e-4 * ref || rmax > 1e-9 * (dmax + 1e-300))) break;
-                        __syncthreads();                               // s_r / s_rho are about to change
+                        __syncthreads();                               // red / s_r / s_rho are about to change
                         if (tid < qhi) {                                // dr = P rho ; r += dr
                             const double dr = myact >= 0 ? Pr.dot(s_prow, s_pt, tid, qhi) : 0.0;
                             s_rho[tid] = dr;
@@ -546,6 +584,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                         }
                         __syncthreads();
                     }
+                    STAMP(5);                               // 5: z, rollout, refinement
                     const bool dependent = !(delta > DEP_TOL_F * spp);
                     // step lengths
                     double t1 = INFINITY;
@@ -574,6 +613,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                     }
                     if (tid < qhi && myact >= 0) s_lam[tid] -= t * s_r[tid];
                     lam_p += t;
+                    STAMP(6);                               // 6: step length, trace, x/lambda update
                     if (full) {
                         // P <- [P + r r'/delta, -r/delta; -r'/delta, 1/delta] in a free slot: with r[slot] := -1
                         // the bordered update is one axpy per old row and one scaled copy for the new row
@@ -595,6 +635,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                         if (nfree > 0) --nfree;
                         qhi = qn;
                         __syncthreads();
+                        STAMP(7);                           // 7: add
                         break;                                          // back to step 1
                     }
                     // partial step: drop blocking constraint l: rank-1 downdate (which also annihilates
@@ -617,6 +658,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                         }
                         ++nfree;
                         __syncthreads();
+                        STAMP(8);                           // 8: drop
                     }
                     { double bb; sp = slack_of<NJ>(pc, xs, s_g, s_rhs, s_lim, s_v0, s_mx, H, &bb); }
                 }
@@ -655,21 +697,38 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
         dx2 = block_sum(dx2, red, tid);
         for (int k = tid; k < HN; k += FT) s_u[k] = xs[k];
         __syncthreads();
-        // cost = 0.5*u'*QQ*u + ff'*u + caug (EVAL.m:52); QQ*u also feeds the next PSG step
-        double cpart = 0.0;
-        for (int k = tid; k < HN; k += FT) {
-            double s = 0.0;
-            for (int c = 0; c < HN; ++c) s += P.QQ[k + (size_t)c * nn] * s_u[c];
-            s_qu[k] = s;
-            cpart += s_u[k] * (0.5 * s + P.ff[(size_t)b * nn + k]);
+        // cost = 0.5*u'*QQ*u + ff'*u + caug (EVAL.m:52).  CFS: the stop test does not depend on it, so u is
+        // logged and the whole cost history is one batched MFMA product after the solve (cfs_gemm.hip).
+        // PSGCFS: QQ*u is needed in the loop (stop_inner and the next gradient step).
+        double cost = cost_new;
+        if (P.u_hist) {
+            for (int k = tid; k < HN; k += FT) P.u_hist[((size_t)b * P.max_o_iter + (iter_O - 1)) * nn + k] = s_u[k];
+            if (tid == 0) P.e_u_all[(size_t)b * P.max_o_iter + (iter_O - 1)] = sqrt(du2);
+        } else {
+            double cpart = 0.0;
+            for (int k = tid; k < HN; k += FT) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int c = 0;
+                for (; c + 4 <= HN; c += 4) {
+                    s0 += P.QQ[k + (size_t)c * nn] * s_u[c];
+                    s1 += P.QQ[k + (size_t)(c + 1) * nn] * s_u[c + 1];
+                    s2 += P.QQ[k + (size_t)(c + 2) * nn] * s_u[c + 2];
+                    s3 += P.QQ[k + (size_t)(c + 3) * nn] * s_u[c + 3];
+                }
+                for (; c < HN; ++c) s0 += P.QQ[k + (size_t)c * nn] * s_u[c];
+                const double s = (s0 + s1) + (s2 + s3);
+                s_qu[k] = s;
+                cpart += s_u[k] * (0.5 * s + P.ff[(size_t)b * nn + k]);
+            }
+            cost = block_sum(cpart, red, tid) + P.caug[b];
+            if (tid == 0) {
+                const size_t o = (size_t)b * P.max_o_iter + (iter_O - 1);
+                P.cost_all[o] = cost;                              // EVAL.m:56-58
+                P.e_cost_all[o] = fabs(cost_old - cost);
+                P.e_u_all[o] = sqrt(du2);
+            }
         }
-        const double cost = block_sum(cpart, red, tid) + P.caug[b];
-        if (tid == 0) {
-            const size_t o = (size_t)b * P.max_o_iter + (iter_O - 1);
-            P.cost_all[o] = cost;                              // EVAL.m:56-58
-            P.e_cost_all[o] = fabs(cost_old - cost);
-            P.e_u_all[o] = sqrt(du2);
-        }
+        STAMP(9);                                           // 9: rollout, cost, history
         cost_new = cost;
         ++iter_O;                                              // CFS_FANUC.m:77
         if (sqrt(dx2) < P.epsilon_O) { done = true; status = CFS_OK_CONVERGED; }     // EVAL.m:64-68
@@ -681,6 +740,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
     for (int e = tid; e < HN; e += FT) P.u[(size_t)b * nn + e] = s_u[e];
     for (int e = tid; e < NX; e += FT) P.x_[(size_t)b * NX + e] = s_x[e];
     if (tid == 0) { P.iter_O[b] = iter_O; P.total_iter[b] = total_iter; P.status[b] = status; }
+    if (P.stamps && tid == 0) for (int k = 0; k < 12; ++k) P.stamps[(size_t)b * 12 + k] = acc_[k];
 }
 
 template <int NJ, int QB>

@@ -95,6 +95,28 @@ __global__ __launch_bounds__(CFS_WAVE) void cfs_outer_update_kernel(OuterParams 
     else if (it > P.max_o_iter) { P.status[b] = CFS_OK_MAXITER; P.done[b] = 1; }       // EVAL.m:69-72
 }
 
+// cost history of a CFS solve from the logged u and QQ*u (EVAL.m:51-59; CFS_FANUC.m:67,73-75): one
+// wavefront per problem; cost_old of iteration k is the cost of iteration k-1, caug (= get_cost(0)) for k = 0.
+__global__ __launch_bounds__(CFS_WAVE) void cfs_cost_history_kernel(CostHistParams P)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, nn = P.nn, n_it = P.iter_O[b] - 1;
+    double prev = P.caug[b];
+    for (int k = 0; k < n_it; ++k) {
+        const double *u = P.u_hist + ((size_t)b * P.max_o_iter + k) * nn;
+        const double *q = P.qu_hist + ((size_t)b * P.max_o_iter + k) * nn;
+        double quad = 0.0, lin = 0.0;
+        for (int e = lane; e < nn; e += CFS_WAVE) { quad += u[e] * q[e]; lin += P.ff[(size_t)b * nn + e] * u[e]; }
+        quad = wsum(quad);
+        lin = wsum(lin);
+        const double cost = 0.5 * quad + lin + P.caug[b];
+        if (lane == 0) {
+            P.cost_all[(size_t)b * P.max_o_iter + k] = cost;
+            P.e_cost_all[(size_t)b * P.max_o_iter + k] = fabs(prev - cost);
+        }
+        prev = cost;
+    }
+}
+
 // constructor state (Lib/CFS_FANUC.m:55-58, Lib/EVAL.m:40-48) and the stop_outer test that precedes
 // the first iteration (CFS_FANUC.m:63-64)
 __global__ __launch_bounds__(CFS_WAVE) void cfs_init_kernel(InitParams P)
@@ -135,6 +157,11 @@ void launch_outer_update(const OuterParams &p, hipStream_t s)
     g.B = p.B; g.nn = p.nn; g.M = p.QQ; g.X = p.u; g.Y = p.qu; g.scale = 1.0;
     launch_batched_gemv(g, s);
     hipLaunchKernelGGL(cfs_outer_update_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
+}
+
+void launch_cost_history(const CostHistParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(cfs_cost_history_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
 }
 
 void launch_init(const InitParams &p, hipStream_t s)
