@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -133,6 +134,7 @@ struct cfs_problem {
     DevRobot hrobot;
     DevBuf<DevRobot> rb;
     DevBuf<double> QQ, Hinv, Hq, M1, M2, M3, M1n, M2n, lim, maxin, margin;
+    DevBuf<double> Mr[6];   // rollouts (Bvel*, Bpos*) of the columns of M1n, M2n, Hq
     // workspace (max_batch problems)
     DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg, Pt, u_hist, qu_hist;
     DevBuf<int> qp_status, qp_iter, noise_row, linkid;
@@ -145,6 +147,7 @@ struct cfs_problem {
         ev.clear();
         rb.release(); QQ.release(); Hinv.release(); Hq.release(); M1.release(); M2.release(); M3.release();
         M1n.release(); M2n.release(); Pt.release(); u_hist.release(); qu_hist.release();
+        for (auto &m : Mr) m.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
         grad.release(); cost_new.release(); cost_old.release(); delta.release(); e_u.release();
         Yg.release(); Tg.release(); qp_status.release(); qp_iter.release(); noise_row.release();
@@ -296,6 +299,26 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
             }
     }
 
+    // rollouts of every family column (double integrator: Bvel w = dt*cumsum(w), Bpos w = sum (i-k+1/2) dt^2 w_k)
+    std::vector<double> Mroll[6];
+    {
+        const std::vector<double> *src[3] = {&M1n, &M2n, &Hq};
+        for (int m = 0; m < 3; ++m) {
+            Mroll[2 * m].assign((size_t)nn * nn, 0.0);
+            Mroll[2 * m + 1].assign((size_t)nn * nn, 0.0);
+            for (int col = 0; col < nn; ++col)
+                for (int c = 0; c < nj; ++c) {
+                    long double sv = 0.0L;
+                    for (int i = 0; i < H; ++i) {
+                        long double sp = 0.0L;
+                        sv += (*src[m])[(i * nj + c) + (size_t)col * nn];
+                        for (int k = 0; k <= i; ++k) sp += ((long double)(i - k) + 0.5L) * (*src[m])[(k * nj + c) + (size_t)col * nn];
+                        Mroll[2 * m][(i * nj + c) + (size_t)col * nn] = (double)((long double)dt * sv);
+                        Mroll[2 * m + 1][(i * nj + c) + (size_t)col * nn] = (double)((long double)dt * (long double)dt * sp);
+                    }
+                }
+        }
+    }
     cfs_problem *p = new (std::nothrow) cfs_problem();
     if (!p) return fail(CFS_ERR_ALLOC, "out of host memory");
     p->d = *desc;
@@ -307,6 +330,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     hipError_t e = hipSetDevice(p->device);
 #define A_(buf, count) if (e == hipSuccess) e = p->buf.alloc(count)
     A_(rb, 1); A_(QQ, (size_t)nn * nn); A_(Hinv, (size_t)nn * nn); A_(M1, (size_t)nn * nn); A_(M2, (size_t)nn * nn);
+    for (int m = 0; m < 6; ++m) { A_(Mr[m], (size_t)nn * nn); }
     A_(M3, (size_t)nn * nn); A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * 64 * 160); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
     A_(cost_new, Bm); A_(cost_old, Bm); A_(delta, Bm); A_(e_u, Bm); A_(Yg, Bm * nn * nn); A_(Tg, Bm * nn * nn);
@@ -317,6 +341,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     U_(rb, &p->hrobot, 1); U_(QQ, desc->QQ, (size_t)nn * nn); U_(Hinv, Hinv.data(), (size_t)nn * nn);
     U_(M1, M1.data(), (size_t)nn * nn); U_(M2, M2.data(), (size_t)nn * nn); U_(M3, M3.data(), (size_t)nn * nn);
     U_(M1n, M1n.data(), (size_t)nn * nn); U_(M2n, M2n.data(), (size_t)nn * nn); U_(Hq, Hq.data(), (size_t)nn * nn);
+    for (int m = 0; m < 6; ++m) { U_(Mr[m], Mroll[m].data(), (size_t)nn * nn); }
     U_(lim, desc->lim, nj); U_(margin, desc->margin, desc->nobs);
     if (desc->mode == CFS_MODE_CFS) { U_(maxin, desc->MAX_input, nn); }
     else if (e == hipSuccess) e = hipMemset(p->maxin.p, 0, nn * sizeof(double));
@@ -379,6 +404,7 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     fp.has_bounds = p->d.mode == CFS_MODE_CFS; fp.max_o_iter = K; fp.noise_rows = in->noise ? in->noise_rows : 0;
     fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O;
     fp.M1 = p->M1n.p; fp.M2 = p->M2n.p; fp.M3 = p->Hq.p; fp.QQ = p->QQ.p;
+    fp.M1v = p->Mr[0].p; fp.M1p = p->Mr[1].p; fp.M2v = p->Mr[2].p; fp.M2p = p->Mr[3].p; fp.M3v = p->Mr[4].p; fp.M3p = p->Mr[5].p;
     fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
     fp.x_init = in->x_init; fp.xR1 = in->xR1; fp.ff = in->ff; fp.caug = in->caug; fp.obs = in->obs; fp.noise = in->noise;
     fp.x0 = p->x0.p;
@@ -388,6 +414,7 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
     fp.stamps = (g_stamps && B <= g_stamps_B) ? g_stamps : nullptr;
     fp.u_hist = (p->d.mode == CFS_MODE_CFS && K > 0) ? p->u_hist.p : nullptr;
+    { const char *e = getenv("CFS_OPT"); fp.opt = e ? atoi(e) : 0; }
     (void)nx;
     HIPCHK(launch_fused(nj, fp, s));
     if (p->prof) {

@@ -131,6 +131,7 @@ struct FusedParams {
     int qy, lin_w;               // filled by launch_fused: Y rows held in LDS, waypoints per linearisation tile
     double dt, alpha, epsilon_O;
     const double *M1, *M2, *M3;  // nn x nn column-major: H^{-1}Bpos', H^{-1}Bvel', H^{-1} (natural row order)
+    const double *M1v, *M1p, *M2v, *M2p, *M3v, *M3p;   // Bvel* and Bpos* of every column of M1, M2, M3
     const double *QQ;            // raw sys_info.QQ
     const double *lim, *maxin, *margin;
     const double *x_init, *xR1, *ff, *caug, *obs, *noise;
@@ -142,6 +143,7 @@ struct FusedParams {
     double *dbg;                 // optional trace: 8 doubles per active-set step of problem dbg_b (developer aid)
     int dbg_b, dbg_cap;
     unsigned long long *stamps;  // optional: 16 cycle accumulators per problem (developer aid)
+    int opt;                     // developer A/B switches (bit 0: gather w only and roll it on the fly)
     double *u_hist;              // CFS: B x max_o_iter x nn log of u per outer iteration (cost history computed afterwards)
 };
 hipError_t launch_fused(int nj, FusedParams p, hipStream_t s);

@@ -25,7 +25,7 @@
 
 namespace {
 
-#define STAMP(k) do { if (P.stamps) { const unsigned long long t_ = clock64(); acc_[k] += t_ - t0_; t0_ = t_; } } while (0)
+#define STAMP(k) do { if (P.stamps) { const unsigned long long t_ = clock64(); if (tid == 0) s_acc[k] += t_ - t0_; t0_ = t_; } } while (0)
 
 constexpr int FT = 256;                  // threads per workgroup
 constexpr double DEP_TOL_F = 1e-8;       // dependent if delta <= tol * n'H^{-1}n: above the eps*cond(H) noise floor of Y = H^{-1}N
@@ -245,7 +245,7 @@ struct PRow {
 };
 
 struct FusedLayout {      // LDS offsets in doubles, computed identically on host and device
-    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, red, small, mx, ptail, y, total_fixed;
+    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, code, red, small, mx, ptail, y, total_fixed;
 };
 __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int QB, int PR)
 {
@@ -270,7 +270,8 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.act = o; o += (QB + 1) / 2;
     L.fre = o; o += (QB + 1) / 2;          // stack of freed slots
     L.flag = o; o += (nobs * H + 4 * HN + 7) / 8;
-    L.red = o; o += 16;
+    L.code = o; o += (nobs * H + 4 * HN + 1) / 2;
+    L.red = o; o += 32;
     L.small = o; o += 4 * NJ + nobs;       // lim, v0, theta0 (2NJ), margin
     L.mx = o; o += HN;                     // MAX_input
     L.ptail = o;                           // (tail columns of P live in global scratch)
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
     int *s_act = reinterpret_cast<int *>(lds + L.act);
     int *s_free = reinterpret_cast<int *>(lds + L.fre);
     unsigned char *s_flag = reinterpret_cast<unsigned char *>(lds + L.flag);
+    int *s_code = reinterpret_cast<int *>(lds + L.code);
     double *red = lds + L.red;
     double *s_lim = lds + L.small, *s_v0 = s_lim + NJ, *s_th0 = s_v0 + NJ, *s_margin = s_th0 + 2 * NJ;
     double *s_mx = lds + L.mx;
@@ -307,6 +309,16 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
     double *Yg = P.Yg + (size_t)b * nn * nn;
     const int ncon = nobs * H + (P.has_bounds ? 4 : 2) * HN;
     const int maxit = 8 * nn + 200;                  // the oracle's longest certificates take ~2 nn steps
+    // constraint codes never change: decoded once into LDS (no integer divisions in the step loop)
+    for (int e = tid; e < ncon; e += FT) {
+        int code;
+        if (e < nobs * H) { const int j = e / H; code = mk_code(CT_COL, e - j * H, j); }
+        else {
+            const int f2 = e - nobs * H, ty = f2 / HN, k = f2 - ty * HN, i = k / NJ;
+            code = mk_code(1 + ty, i, k - i * NJ);
+        }
+        s_code[e] = code;
+    }
 
     // ---- constructor state (CFS_FANUC.m:55-58, EVAL.m:40-48) ------------------------------------
     {
@@ -323,7 +335,9 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
         if (tid < nobs) s_margin[tid] = P.margin[tid];
     }
     __syncthreads();
-    unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_ = P.stamps ? clock64() : 0ull;
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(red + 20);   // 12 phase accumulators (developer aid)
+    if (tid < 12) s_acc[tid] = 0ull;
+    unsigned long long t0_ = P.stamps ? clock64() : 0ull;
     double cost_new = P.caug[b], cost_old = 100000.0;      // get_cost(zeros) = caug; EVAL.m:29
     int iter_O = 1, total_iter = 0, noise_row = 0, status = CFS_OK_MAXITER;
     bool done = false;
@@ -475,17 +489,13 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
             STAMP(1);                                       // 1: QP setup
             for (;;) {
                 if (fgain > fbound) { qp_status = QP_INFEASIBLE; break; }
-                // step 1: most violated constraint (constraints are strided over the threads)
+                // step 1: most violated constraint (constraints are strided over the threads; the codes of a
+                // thread's constraints never change, so they are decoded once per kernel -- no integer divisions here)
                 double sbest = 0.0;
                 int cbest = 0x7fffffff;
                 for (int e = tid; e < ncon; e += FT) {
                     if (s_flag[e]) continue;
-                    int code;
-                    if (e < nobs * H) { const int j = e / H; code = mk_code(CT_COL, e - j * H, j); }
-                    else {
-                        const int f = e - nobs * H, ty = f / HN, k = f - ty * HN, i = k / NJ;
-                        code = mk_code(1 + ty, i, k - i * NJ);
-                    }
+                    const int code = s_code[e];
                     double bb;
                     const double sl = slack_of<NJ>(code, xs, s_g, s_rhs, s_lim, s_v0, s_mx, H, &bb);
                     if (sl < -1e-11 * (1.0 + fabs(bb)) && sl < sbest) { sbest = sl; cbest = code; }
@@ -500,23 +510,31 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                 // step 2
                 for (;;) {
                     if (++iters > maxit) { qp_status = QP_NUMERIC; break; }
-                    // w = H^{-1} n_p (gather of <= NJ family columns), its rollout, d = N'w
+                    // w = H^{-1} n_p together with its rollouts (Bvel w, Bpos w): a gather of <= NJ columns of the
+                    // family matrices and of their precomputed rollouts -- no prefix sums, one barrier
                     for (int k = tid; k < HN; k += FT) {
-                        double w;
+                        double w0, w1, w2;
                         if (ptype == CT_COL) {
-                            w = 0.0;
+                            w0 = w1 = w2 = 0.0;
 #pragma unroll
-                            for (int cs = 0; cs < NJ; ++cs) w += s_g[(pj * H + pi) * NJ + cs] * P.M1[(size_t)(pi * NJ + cs) * nn + k];
+                            for (int cs = 0; cs < NJ; ++cs) {
+                                const double gc = s_g[(pj * H + pi) * NJ + cs];
+                                const size_t o = (size_t)(pi * NJ + cs) * nn + k;
+                                w0 += gc * P.M1[o];
+                                if (!(P.opt & 1)) { w1 += gc * P.M1v[o]; w2 += gc * P.M1p[o]; }
+                            }
                         } else {
-                            const double *Mx = (ptype == CT_VELP || ptype == CT_VELM) ? P.M2 : P.M3;
+                            const bool vel = ptype == CT_VELP || ptype == CT_VELM;
                             const double sg = (ptype == CT_VELP || ptype == CT_BNDP) ? -1.0 : 1.0;
-                            w = sg * Mx[(size_t)(pi * NJ + pj) * nn + k];
+                            const size_t o = (size_t)(pi * NJ + pj) * nn + k;
+                            w0 = sg * (vel ? P.M2 : P.M3)[o];
+                            w1 = w2 = 0.0;
+                            if (!(P.opt & 1)) { w1 = sg * (vel ? P.M2v : P.M3v)[o]; w2 = sg * (vel ? P.M2p : P.M3p)[o]; }
                         }
-                        wb[k] = w;
+                        wb[k] = w0; wb[HN + k] = w1; wb[2 * HN + k] = w2;
                     }
                     __syncthreads();
-                    roll_lds<NJ>(wb, H, dt, tid);
-                    __syncthreads();
+                    if (P.opt & 1) { roll_lds<NJ>(wb, H, dt, tid); __syncthreads(); }
                     STAMP(3);                               // 3: w gather + rollout
                     const double spp = ndot<NJ>(pc, wb, s_g, H);
                     const int myact = tid < qhi ? s_act[tid] : -1;
@@ -527,7 +545,8 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                     __syncthreads();
                     STAMP(4);                               // 4: d = N'w, r = P d
                     // z = w - Y'r, rollout, then iterative refinement against the true Gram matrix
-                    double delta = 0.0;
+                    double delta = 0.0, t1 = INFINITY;
+                    int l = 0x7fffffff;
                     for (int pass = 0; pass < 4; ++pass) {
                         const double *coef = pass == 0 ? s_r : s_rho;      // pass>0: correction dr held in s_rho
                         const int qa = min(qhi, QY);
@@ -554,28 +573,40 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                         roll_lds<NJ>(zb, H, dt, tid);
                         __syncthreads();
                         delta = ndot<NJ>(pc, zb, s_g, H);              // n_p'z
-                        if (qhi == nfree || pass == 3) break;
-                        // residual rho_a = n_a'z (zero in exact arithmetic)
-                        double rr = 0.0, rmax = 0.0, dmax = 0.0;
-                        if (tid < qhi) {
-                            const double ra = myact >= 0 ? ndot<NJ>(myact, zb, s_g, H) : 0.0;
+                        if (qhi == nfree) break;                       // empty active set: nothing to refine, t1 = inf
+                        // one exchange carries the refinement diagnostics (r'rho, max|rho|, max|d|; rho_a = n_a'z is
+                        // zero in exact arithmetic) and the dual step length t1 = min{lambda_a / r_a : r_a > 0}
+                        double rr = 0.0, rmax = 0.0, dmax = 0.0, t1c = INFINITY;
+                        if (tid < qhi && myact >= 0) {
+                            const double ra = ndot<NJ>(myact, zb, s_g, H), rv = s_r[tid];
                             s_prow[tid] = ra;
-                            rr = s_r[tid] * ra;
+                            rr = rv * ra;
                             rmax = fabs(ra);
                             dmax = fabs(s_d[tid]);
-                        }
-                        // r'rho, max|rho|, max|d| over the active set: one wave reduction each + one LDS exchange
+                            if (rv > 0.0) t1c = s_lam[tid] / rv;
+                        } else if (tid < qhi) s_prow[tid] = 0.0;
                         rr = wave_add(rr);
                         rmax = -wave_min(-rmax);
                         dmax = -wave_min(-dmax);
+                        const double t1w = wave_min(t1c);
+                        const unsigned long long hit = __ballot(t1c == t1w);
+                        const int lw = (tid & ~63) + (hit ? (int)__builtin_ctzll(hit) : 0);
                         __syncthreads();
-                        if ((tid & 63) == 0) { red[tid >> 6] = rr; red[4 + (tid >> 6)] = rmax; red[8 + (tid >> 6)] = dmax; }
+                        if ((tid & 63) == 0) {
+                            const int wv = tid >> 6;
+                            red[wv] = rr; red[4 + wv] = rmax; red[8 + wv] = dmax; red[12 + wv] = t1w;
+                            reinterpret_cast<int *>(red + 16)[wv] = lw;
+                        }
                         __syncthreads();
                         rr = (red[0] + red[1]) + (red[2] + red[3]);
                         rmax = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
                         dmax = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+                        t1 = red[12]; l = reinterpret_cast<int *>(red + 16)[0];
+#pragma unroll
+                        for (int w = 1; w < 4; ++w)
+                            if (red[12 + w] < t1) { t1 = red[12 + w]; l = reinterpret_cast<int *>(red + 16)[w]; }
                         const double ref = fmax(fabs(delta), DEP_TOL_F * spp);
-                        if (!(fabs(rr) > 1e-4 * ref || rmax > 1e-9 * (dmax + 1e-300))) break;
+                        if (pass == 3 || !(fabs(rr) > 1e-4 * ref || rmax > 1e-9 * (dmax + 1e-300))) break;
                         __syncthreads();                               // red / s_r / s_rho are about to change
                         if (tid < qhi) {                                // dr = P rho ; r += dr
                             const double dr = myact >= 0 ? Pr.dot(s_prow, s_pt, tid, qhi) : 0.0;
@@ -584,16 +615,8 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                         }
                         __syncthreads();
                     }
-                    STAMP(5);                               // 5: z, rollout, refinement
+                    STAMP(5);                               // 5: z, rollout, refinement, dual step length
                     const bool dependent = !(delta > DEP_TOL_F * spp);
-                    // step lengths
-                    double t1 = INFINITY;
-                    int l = 0x7fffffff;
-                    if (tid < qhi && myact >= 0) {
-                        const double ra = s_r[tid];
-                        if (ra > 0.0) { t1 = s_lam[tid] / ra; l = tid; }
-                    }
-                    block_argmin(t1, l, red, tid);
                     const double t2 = dependent ? INFINITY : -sp / delta;
                     const double t = fmin(t1, t2);
                     if (P.dbg && b == P.dbg_b && tid == 0) {
@@ -707,16 +730,14 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
         } else {
             double cpart = 0.0;
             for (int k = tid; k < HN; k += FT) {
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                double sa[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                 int c = 0;
-                for (; c + 4 <= HN; c += 4) {
-                    s0 += P.QQ[k + (size_t)c * nn] * s_u[c];
-                    s1 += P.QQ[k + (size_t)(c + 1) * nn] * s_u[c + 1];
-                    s2 += P.QQ[k + (size_t)(c + 2) * nn] * s_u[c + 2];
-                    s3 += P.QQ[k + (size_t)(c + 3) * nn] * s_u[c + 3];
+                for (; c + 8 <= HN; c += 8) {                   // 8 independent L2 loads in flight per thread
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sa[j] += P.QQ[k + (size_t)(c + j) * nn] * s_u[c + j];
                 }
-                for (; c < HN; ++c) s0 += P.QQ[k + (size_t)c * nn] * s_u[c];
-                const double s = (s0 + s1) + (s2 + s3);
+                for (; c < HN; ++c) sa[0] += P.QQ[k + (size_t)c * nn] * s_u[c];
+                const double s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
                 s_qu[k] = s;
                 cpart += s_u[k] * (0.5 * s + P.ff[(size_t)b * nn + k]);
             }
@@ -740,7 +761,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
     for (int e = tid; e < HN; e += FT) P.u[(size_t)b * nn + e] = s_u[e];
     for (int e = tid; e < NX; e += FT) P.x_[(size_t)b * NX + e] = s_x[e];
     if (tid == 0) { P.iter_O[b] = iter_O; P.total_iter[b] = total_iter; P.status[b] = status; }
-    if (P.stamps && tid == 0) for (int k = 0; k < 12; ++k) P.stamps[(size_t)b * 12 + k] = acc_[k];
+    if (P.stamps && tid == 0) for (int k = 0; k < 12; ++k) P.stamps[(size_t)b * 12 + k] = s_acc[k];
 }
 
 template <int NJ, int QB>
