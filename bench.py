@@ -52,9 +52,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (not used by the driver): CFS_BENCH_BACKEND=gloo runs the collective on CPU copies,
+    # CFS_BENCH_DEVICE=0 lets several ranks share one GPU on a one-GPU box
+    backend = os.environ.get("CFS_BENCH_BACKEND", "nccl")
+    if "CFS_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["CFS_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -73,8 +78,10 @@ def main():
     def step():
         slv.solve_device(x_init, xR1, ff, caug, obs, noise=noise, out=out)
         if world > 1:   # the path's one exchange: all-gather of the converged trajectories (s_Parallel_rrt.m:16-28)
-            parallel.gather_results(dict(u=out.u, x_=out.x_, status=out.status, iter_O=out.iter_O,
-                                         cost=out.cost_all[:, -1].contiguous()), B * world)
+            loc = dict(u=out.u, x_=out.x_, status=out.status, iter_O=out.iter_O, cost=out.cost_all[:, -1].contiguous())
+            if backend != "nccl":
+                loc = {k: v.cpu() for k, v in loc.items()}
+            parallel.gather_results(loc, B * world)
 
     def fence():
         if world > 1:
@@ -97,6 +104,8 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     usum = torch.tensor([float(units_step)], dtype=torch.float64, device=dev)
     if world > 1:
+        if backend != "nccl":
+            tmax, usum = tmax.cpu(), usum.cpu()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(usum, op=dist.ReduceOp.SUM)
     dt_max, units_all = float(tmax.item()), float(usum.item())
