@@ -18,7 +18,7 @@ except Exception:  # pragma: no cover - torch is optional for the host-pointer e
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcfs_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("CFS_LIBNAME", "libcfs_hip.so"))   # CFS_LIBNAME: developer A/B builds
 
 CFS_MAX_LINKS = 8
 CFS_MAX_OBS = 32

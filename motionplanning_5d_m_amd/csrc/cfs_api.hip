@@ -331,7 +331,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
 #define A_(buf, count) if (e == hipSuccess) e = p->buf.alloc(count)
     A_(rb, 1); A_(QQ, (size_t)nn * nn); A_(Hinv, (size_t)nn * nn); A_(M1, (size_t)nn * nn); A_(M2, (size_t)nn * nn);
     for (int m = 0; m < 6; ++m) { A_(Mr[m], (size_t)nn * nn); }
-    A_(M3, (size_t)nn * nn); A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * 64 * 160); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
+    A_(M3, (size_t)nn * nn); A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * 128 * 160); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
     A_(cost_new, Bm); A_(cost_old, Bm); A_(delta, Bm); A_(e_u, Bm); A_(Yg, Bm * nn * nn); A_(Tg, Bm * nn * nn);
     if (desc->mode == CFS_MODE_CFS) { A_(u_hist, Bm * (size_t)desc->MAX_O_ITER * nn); A_(qu_hist, Bm * (size_t)desc->MAX_O_ITER * nn); }

@@ -27,6 +27,9 @@ namespace {
 
 #define STAMP(k) do { if (P.stamps) { const unsigned long long t_ = clock64(); if (tid == 0) s_acc[k] += t_ - t0_; t0_ = t_; } } while (0)
 
+#ifndef CFS_PR
+#define CFS_PR 64                        // columns of each inverse-Gram row kept in registers
+#endif
 constexpr int FT = 256;                  // threads per workgroup
 constexpr double DEP_TOL_F = 1e-8;       // dependent if delta <= tol * n'H^{-1}n: above the eps*cond(H) noise floor of Y = H^{-1}N
 enum { CT_COL = 0, CT_VELP = 1, CT_VELM = 2, CT_BNDP = 3, CT_BNDM = 4 };
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
     const int b = blockIdx.x, tid = threadIdx.x;
     const int H = P.H, nobs = P.nobs, HN = H * NJ, nn = HN, NX = H * NS;
     const double dt = P.dt;
-    constexpr int PR = QB < 96 ? QB : 96;   // register-resident columns of each P row (rest: global scratch)
+    constexpr int PR = QB < CFS_PR ? QB : CFS_PR;   // register-resident columns of each P row (rest: global scratch)
     const FusedLayout L = fused_layout(NJ, H, nobs, QB, PR);
     DevRobot *rb = reinterpret_cast<DevRobot *>(lds + L.rb);
     double *s_ob = lds + L.ob, *s_x = lds + L.x, *s_u = lds + L.u, *s_qu = lds + L.qu, *s_g = lds + L.g;
@@ -785,7 +788,7 @@ hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
 {
     const int nn = p.H * nj;
     const int QB = nn <= 96 ? 96 : 160;
-    const FusedLayout L = fused_layout(nj, p.H, p.nobs, QB, QB < 96 ? QB : 96);
+    const FusedLayout L = fused_layout(nj, p.H, p.nobs, QB, QB < CFS_PR ? QB : CFS_PR);
     const size_t avail = (160 * 1024) / 8 - 64;             // doubles per workgroup, small safety margin
     if ((size_t)L.total_fixed + 4 * nn > avail) return hipErrorInvalidValue;
     const size_t region = avail - L.total_fixed;
