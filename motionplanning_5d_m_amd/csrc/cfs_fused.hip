@@ -27,6 +27,9 @@ namespace {
 
 #define STAMP(k) do { if (P.stamps) { const unsigned long long t_ = clock64(); if (tid == 0) s_acc[k] += t_ - t0_; t0_ = t_; } } while (0)
 
+#ifndef CFS_WG_PER_CU
+#define CFS_WG_PER_CU 1                   // workgroups resident per CU (2: half the LDS and registers each)
+#endif
 #ifndef CFS_PR
 #define CFS_PR 64                        // columns of each inverse-Gram row kept in registers
 #endif
@@ -286,7 +289,7 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
 
 // ------------------------------------------------------------------------------------------------
 template <int NJ, int QB>
-__global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
+__global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(FusedParams P)
 {
     constexpr int NS = 2 * NJ, NVT = nvt(NJ), NE = 2 * NJ + 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(FT) void cfs_solve_fused_kernel(FusedParams P)
                         for (int w = 1; w < 4; ++w)
                             if (red[12 + w] < t1) { t1 = red[12 + w]; l = reinterpret_cast<int *>(red + 16)[w]; }
                         const double ref = fmax(fabs(delta), DEP_TOL_F * spp);
-                        if (pass == 3 || !(fabs(rr) > 1e-4 * ref || rmax > 1e-9 * (dmax + 1e-300))) break;
+                        if (pass == 3 || (P.opt & 2) || !(fabs(rr) > 1e-4 * ref || rmax > 1e-9 * (dmax + 1e-300))) break;
                         __syncthreads();                               // red / s_r / s_rho are about to change
                         if (tid < qhi) {                                // dr = P rho ; r += dr
                             const double dr = myact >= 0 ? Pr.dot(s_prow, s_pt, tid, qhi) : 0.0;
@@ -789,7 +792,7 @@ hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
     const int nn = p.H * nj;
     const int QB = nn <= 96 ? 96 : 160;
     const FusedLayout L = fused_layout(nj, p.H, p.nobs, QB, QB < CFS_PR ? QB : CFS_PR);
-    const size_t avail = (160 * 1024) / 8 - 64;             // doubles per workgroup, small safety margin
+    const size_t avail = (160 * 1024 / CFS_WG_PER_CU) / 8 - 64;   // doubles per workgroup, small safety margin
     if ((size_t)L.total_fixed + 4 * nn > avail) return hipErrorInvalidValue;
     const size_t region = avail - L.total_fixed;
     int qy = (int)(region / nn);
