@@ -224,6 +224,8 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     if (!desc->QQ || !desc->lim || !desc->margin) return fail(CFS_ERR_INVALID_ARG, "QQ/lim/margin must be given");
     if (desc->mode == CFS_MODE_CFS && !desc->MAX_input) return fail(CFS_ERR_INVALID_ARG, "MAX_input must be given in CFS mode");
     if (desc->max_batch < 1) return fail(CFS_ERR_INVALID_ARG, "max_batch must be >= 1");
+    if (!fused_fits(nj, H, desc->nobs))
+        return fail(CFS_ERR_INVALID_ARG, "H=%d x nobs=%d x njoint=%d exceeds the 160 KB on-chip budget of one problem (nobs*H*njoint*8 B of gradients must fit next to the solver state)", H, desc->nobs, nj);
     if (desc->MAX_O_ITER < 0) return fail(CFS_ERR_INVALID_ARG, "MAX_O_ITER must be >= 0");
     const double dt = desc->robot.delta_t;
     if (!(dt > 0)) return fail(CFS_ERR_INVALID_ARG, "robot.delta_t must be positive");

@@ -147,6 +147,7 @@ struct FusedParams {
     double *u_hist;              // CFS: B x max_o_iter x nn log of u per outer iteration (cost history computed afterwards)
 };
 hipError_t launch_fused(int nj, FusedParams p, hipStream_t s);
+bool fused_fits(int nj, int H, int nobs);
 
 struct CostHistParams {          // EVAL.get_cost / store_result for a logged u history (CFS mode)
     int B, nn, max_o_iter;

@@ -786,6 +786,17 @@ hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
 
 }  // namespace
 
+// does the fused kernel's fixed LDS footprint (+ a minimal Y / linearisation region) fit a CU?
+bool fused_fits(int nj, int H, int nobs)
+{
+    const int nn = H * nj;
+    const int QB = nn <= 96 ? 96 : 160;
+    const FusedLayout L = fused_layout(nj, H, nobs, QB, QB < CFS_PR ? QB : CFS_PR);
+    const size_t avail = (160 * 1024 / CFS_WG_PER_CU) / 8 - 64;
+    const size_t per_wp = (size_t)nj * 7 + (size_t)nvt(nj) * (18 + nobs);
+    return (size_t)L.total_fixed + std::max((size_t)4 * nn, per_wp) <= avail;
+}
+
 // host: choose the capacities, fill qy / lin_w, launch
 hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
 {

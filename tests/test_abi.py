@@ -68,3 +68,17 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
                 assert "cfs_oracle" not in txt and "libcfs_oracle" not in txt, f
+
+
+def test_on_chip_budget_is_checked_before_the_device():
+    # H=64 x nobs=32 x 5 joints needs 82 KB for the gradients alone: rejected with a clear message, no crash
+    R, s, obs = pkg.main_FANUC_problem()
+    big = pkg.build_sys_info(s.robot, 5, 64, np.zeros(5), np.ones(5) * 0.1, pkg.line_reference(np.zeros(5), np.ones(5) * 0.1, 64),
+                             Qp=np.eye(5), Qv=np.eye(5), Rblk=np.eye(5), cR=1.0, lim=np.ones(5), max_input_blk=np.ones(5),
+                             epsilon_O=0.1, MAX_O_ITER=5)
+    with pytest.raises(pkg.CfsError) as e:
+        pkg.CFSBatch(big, 32, [0.2] * 32)
+    assert e.value.code == -1 and "on-chip budget" in str(e.value)
+    with pytest.raises(pkg.CfsError) as e:
+        pkg.CFSBatch(s, 33, [0.2] * 33)               # nobs > CFS_MAX_OBS
+    assert e.value.code == -1

@@ -178,3 +178,44 @@ def test_zero_iterations_and_max_iter_edge(gpu):
     s1 = copy.copy(s); s1.MAX_O_ITER = 1
     got = gpu.CFS_FANUC(obs, s1, R).optimizer()
     assert got.status == 1 and got.iter_O == 2 and len(got.eval.cost_all) == 1
+
+
+def test_maximum_horizon_and_many_obstacles(gpu, O):
+    # H = 64 (CFS_MAX_H), 12 obstacles, M16iB kinematics: the largest shape that fits one CU's LDS next to the solver state
+    robot, orobot = gpu.robotproperty2("M16iB"), O.robotproperty2("M16iB")
+    th0 = np.array([0.5, 1.2, 0.1, 0.0, -1.2]); th1 = np.array([-0.4, 1.1, 0.2, 0.1, -1.0])
+    kw = dict(Qp=np.diag([10.0, 10, 1, 1, 1]), Qv=np.diag([10.0, 10, 1, 1, 1]), Rblk=np.eye(5) * 2, cR=50.0, lim=np.ones(5),
+              max_input_blk=np.ones(5), epsilon_O=0.1, MAX_O_ITER=8)
+    s = gpu.build_sys_info(robot, 5, 64, th0, th1, gpu.line_reference(th0, th1, 64), **kw)
+    t = O.build_sys_info(orobot, 5, 64, th0, th1, O.line_reference(th0, th1, 64), **kw)
+    rng = np.random.default_rng(2)
+    obs = []
+    for k in range(12):
+        ang, rad = rng.uniform(0, 2 * np.pi), rng.uniform(0.9, 1.5)      # converges at step 7 with 20 active-set steps
+        x, y = 3250 + 1000 * rad * np.cos(ang), 8500 + 1000 * rad * np.sin(ang)
+        obs.append(gpu.cylinder((x, y, 1), (x, y, rng.uniform(600, 1500)), 0.2, 0.3))
+    got = gpu.CFS_FANUC(obs, s, "M16iB").optimizer()
+    want = O.optimizer("M16iB", t, [dict(l=o["l"], D=o["D"], epsilon=o["epsilon"]) for o in obs], "CFS")
+    assert got.status == want.status and got.iter_O == want.iter_O
+    assert np.abs(got.x_ - want.x_).max() < TOL_RAD and got.x_.shape == (64 * 10,)
+
+
+def test_single_obstacle_short_horizon_and_ragged_batch(gpu, O):
+    # H = 3, one obstacle, batch of 3 (not a multiple of anything), PSGCFS without noise (noise = NULL -> zeros)
+    robot, orobot = gpu.robotproperty2("M200i"), O.robotproperty2("M200i")
+    kw = dict(Qp=np.diag([10.0, 10, 1, 1, 1]), Qv=np.diag([10.0, 10, 1, 1, 1]), Rblk=np.eye(5) * 2, cR=50.0, lim=np.ones(5),
+              max_input_blk=np.ones(5), epsilon_O=0.1, MAX_O_ITER=4)
+    x0 = np.array([0.7825, 0.0284, 0.2172, 0.1444, -1.1779])
+    starts = [x0, x0 + 0.05, x0 - 0.03]
+    goals = [x0 * np.array([0.9, 1, 1, 1, 1]), x0 + 0.1, x0 * 0.95]
+    sys_g = [gpu.build_sys_info(robot, 5, 3, a, b, gpu.line_reference(a, b, 3), **kw) for a, b in zip(starts, goals)]
+    sys_o = [O.build_sys_info(orobot, 5, 3, a, b, O.line_reference(a, b, 3), **kw) for a, b in zip(starts, goals)]
+    ob = [gpu.cylinder((3806, 8413, 1), (3606, 8413, 1038), 0.2, 0.25)]
+    slv = gpu.CFSBatch(sys_g[0], 1, [0.2], mode="PSGCFS", max_batch=8)
+    got = slv.solve(np.stack([s.x_ for s in sys_g]), np.stack([s.xR[:, 0] for s in sys_g]), np.stack([s.ff for s in sys_g]),
+                    np.array([s.caug for s in sys_g]), np.stack([gpu.obs_to_array(ob)] * 3))
+    for b in range(3):
+        want = O.optimizer("M200i", sys_o[b], [dict(l=ob[0]["l"], D=0.2, epsilon=0.25)], "PSGCFS", noise=None)
+        assert got.status[b] == want.status and got.iter_O[b] == want.iter_O
+        assert np.abs(got.x_[b] - want.x_).max() < TOL_RAD
+        np.testing.assert_allclose(got.cost_all[b, :want.iter_O - 1], want.cost_all, rtol=1e-9)
