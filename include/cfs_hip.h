@@ -146,6 +146,18 @@ int cfs_solve_batch(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out 
  * in->B <= max_batch.  This is the entry bench.py times (inputs resident in HBM). */
 int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream);
 
+/* ---- per-problem setup on the device (row f2 of the scope table) ---------------------------------------
+ * replaces, for B (start, goal) pairs at once: the straight-line reference of main_FANUC.m:38-49
+ * (x_ = joint-space line, zero velocities, waypoint 0 dropped), xR(:,1) = [x0; 0] and the cost terms
+ * ff = ((Aaug*xR(:,1)-gaug)'*Qaug*Baug)' and caug = (Aaug*xR(:,1)-gaug)'*Qaug*(Aaug*xR(:,1)-gaug) with
+ * gaug = kron(ones(H,1),[xg;0])  (main_FANUC.m:98-103).
+ * cfs_set_state_cost: Qaug = the drivers' state-cost matrix (H*nstate x H*nstate, column-major, HOST pointer;
+ * main_FANUC.m:79-84), given once per handle.  cfs_build_terms_device: x0, xg: B x njoint (DEVICE);
+ * outputs (DEVICE): x_init B x H*nstate, xR1 B x nstate, ff B x nn, caug B; enqueued on `stream`. */
+int cfs_set_state_cost(cfs_problem *p, const double *Qaug);
+int cfs_build_terms_device(cfs_problem *p, int B, const double *x0, const double *xg,
+                           double *x_init, double *xR1, double *ff, double *caug, void *stream);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * When enabled, cfs_solve_batch_device brackets each kernel launch with hipEvents recorded on the
  * caller's stream (the reference has only tic/toc around the solver calls, main_FANUC.m:140-152).

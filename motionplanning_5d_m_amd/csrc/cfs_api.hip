@@ -134,6 +134,7 @@ struct cfs_problem {
     DevRobot hrobot;
     DevBuf<DevRobot> rb;
     DevBuf<double> QQ, Hinv, Hq, M1, M2, M3, M1n, M2n, lim, maxin, margin;
+    DevBuf<double> F1, F2, Cq;   // per-problem cost terms from (x0, xg), set by cfs_set_state_cost
     DevBuf<double> Mr[6];   // rollouts (Bvel*, Bpos*) of the columns of M1n, M2n, Hq
     // workspace (max_batch problems)
     DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg, Pt, u_hist, qu_hist;
@@ -148,6 +149,7 @@ struct cfs_problem {
         rb.release(); QQ.release(); Hinv.release(); Hq.release(); M1.release(); M2.release(); M3.release();
         M1n.release(); M2n.release(); Pt.release(); u_hist.release(); qu_hist.release();
         for (auto &m : Mr) m.release();
+        F1.release(); F2.release(); Cq.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
         grad.release(); cost_new.release(); cost_old.release(); delta.release(); e_u.release();
         Yg.release(); Tg.release(); qp_status.release(); qp_iter.release(); noise_row.release();
@@ -479,6 +481,64 @@ int cfs_solve_batch(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out 
     st.down(out->total_iter, dout.total_iter, B);
     st.down(out->status, dout.status, B);
     if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+int cfs_set_state_cost(cfs_problem *p, const double *Qaug)
+{
+    if (!p || !Qaug) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(p->device));
+    const int H = p->d.H, nj = p->d.njoint, ns = 2 * nj, nn = p->nn, nx = p->nx;
+    const double dt = p->d.robot.delta_t;
+    // E = [Aaug(:,1:nj), -G] (nx x 2nj): state error per unit of x0 / xg;  QE = Qaug*E;  F = Baug'*QE;  Cq = E'*QE
+    std::vector<long double> E((size_t)nx * 2 * nj, 0.0L), QE((size_t)nx * 2 * nj, 0.0L);
+    for (int i = 0; i < H; ++i)
+        for (int c = 0; c < nj; ++c) {
+            E[(i * ns + c) + (size_t)c * nx] = 1.0L;                      // A^i(1:nj,1:nj) = I  (x0 has zero velocity)
+            E[(i * ns + c) + (size_t)(nj + c) * nx] = -1.0L;              // -gaug
+        }
+    for (int col = 0; col < 2 * nj; ++col)
+        for (int r = 0; r < nx; ++r) {
+            long double s = 0.0L;
+            for (int k = 0; k < nx; ++k) s += (long double)Qaug[r + (size_t)k * nx] * E[k + (size_t)col * nx];
+            QE[r + (size_t)col * nx] = s;
+        }
+    std::vector<double> F1((size_t)nn * nj), F2((size_t)nn * nj), Cq((size_t)4 * nj * nj);
+    for (int col = 0; col < 2 * nj; ++col) {
+        for (int k = 0; k < H; ++k)
+            for (int c = 0; c < nj; ++c) {                              // row (k,c) of Baug': sum over waypoints i >= k
+                long double s = 0.0L;
+                for (int i = k; i < H; ++i)
+                    s += ((long double)(i - k) + 0.5L) * dt * dt * QE[(i * ns + c) + (size_t)col * nx] + (long double)dt * QE[(i * ns + nj + c) + (size_t)col * nx];
+                if (col < nj) F1[(k * nj + c) + (size_t)col * nn] = (double)s;
+                else F2[(k * nj + c) + (size_t)(col - nj) * nn] = (double)(-s);   // ff = F1*x0 - F2*xg
+            }
+        for (int r = 0; r < 2 * nj; ++r) {
+            long double s = 0.0L;
+            for (int k = 0; k < nx; ++k) s += E[k + (size_t)r * nx] * QE[k + (size_t)col * nx];
+            Cq[r + (size_t)col * 2 * nj] = (double)s;
+        }
+    }
+    p->F1.release(); p->F2.release(); p->Cq.release();
+    HIPCHK(p->F1.alloc(F1.size())); HIPCHK(p->F2.alloc(F2.size())); HIPCHK(p->Cq.alloc(Cq.size()));
+    HIPCHK(hipMemcpy(p->F1.p, F1.data(), F1.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->F2.p, F2.data(), F2.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->Cq.p, Cq.data(), Cq.size() * 8, hipMemcpyHostToDevice));
+    return CFS_SUCCESS;
+}
+
+int cfs_build_terms_device(cfs_problem *p, int B, const double *x0, const double *xg,
+                           double *x_init, double *xR1, double *ff, double *caug, void *stream)
+{
+    if (!p || !x0 || !xg || !x_init || !xR1 || !ff || !caug) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    if (B < 1) return fail(CFS_ERR_INVALID_ARG, "B must be >= 1");
+    if (!p->F1.p) return fail(CFS_ERR_INVALID_ARG, "call cfs_set_state_cost first");
+    HIPCHK(hipSetDevice(p->device));
+    TermsParams t;
+    t.B = B; t.H = p->d.H; t.nj = p->d.njoint; t.F1 = p->F1.p; t.F2 = p->F2.p; t.Cq = p->Cq.p;
+    t.x0 = x0; t.xg = xg; t.x_init = x_init; t.xR1 = xR1; t.ff = ff; t.caug = caug;
+    launch_build_terms(t, reinterpret_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
     return CFS_SUCCESS;
 }
 

@@ -158,6 +158,15 @@ struct CostHistParams {          // EVAL.get_cost / store_result for a logged u 
 };
 void launch_cost_history(const CostHistParams &p, hipStream_t s);
 
+struct TermsParams {             // per-problem line reference and cost terms from (x0, xg)
+    int B, H, nj;
+    const double *F1, *F2;       // nn x nj column-major: Baug'*Qaug*Aaug(:,1:nj), Baug'*Qaug*G
+    const double *Cq;            // 2nj x 2nj column-major: E'*Qaug*E, E = [Aaug(:,1:nj), -G]
+    const double *x0, *xg;       // B x nj
+    double *x_init, *xR1, *ff, *caug;
+};
+void launch_build_terms(const TermsParams &p, hipStream_t s);
+
 struct InitParams {
     int B, nn, nx, mode, max_o_iter;
     double epsilon_O;

@@ -117,6 +117,32 @@ __global__ __launch_bounds__(CFS_WAVE) void cfs_cost_history_kernel(CostHistPara
     }
 }
 
+// line reference + cost terms of B (start, goal) pairs (main_FANUC.m:38-49, :98-103); one wavefront per problem
+__global__ __launch_bounds__(CFS_WAVE) void cfs_build_terms_kernel(TermsParams P)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, nj = P.nj, H = P.H, nn = H * nj, ns = 2 * nj;
+    const double *x0 = P.x0 + (size_t)b * nj, *xg = P.xg + (size_t)b * nj;
+    for (int k = lane; k < nn; k += CFS_WAVE) {
+        double s = 0.0;
+        for (int c = 0; c < nj; ++c) s += P.F1[k + (size_t)c * nn] * x0[c] - P.F2[k + (size_t)c * nn] * xg[c];
+        P.ff[(size_t)b * nn + k] = s;
+    }
+    for (int e = lane; e < H * ns; e += CFS_WAVE) {            // linspace(x0, xg, H+1), waypoint 0 dropped, zero velocities
+        const int i = e / ns, c = e - i * ns;
+        double v = 0.0;
+        if (c < nj) v = (i == H - 1) ? xg[c] : x0[c] + (double)(i + 1) * ((xg[c] - x0[c]) / (double)H);
+        P.x_init[(size_t)b * H * ns + e] = v;
+    }
+    if (lane < ns) P.xR1[(size_t)b * ns + lane] = lane < nj ? x0[lane] : 0.0;
+    if (lane == 0) {
+        double q = 0.0;
+        for (int r = 0; r < 2 * nj; ++r)
+            for (int c = 0; c < 2 * nj; ++c)
+                q += (r < nj ? x0[r] : xg[r - nj]) * P.Cq[r + (size_t)c * 2 * nj] * (c < nj ? x0[c] : xg[c - nj]);
+        P.caug[b] = q;
+    }
+}
+
 // constructor state (Lib/CFS_FANUC.m:55-58, Lib/EVAL.m:40-48) and the stop_outer test that precedes
 // the first iteration (CFS_FANUC.m:63-64)
 __global__ __launch_bounds__(CFS_WAVE) void cfs_init_kernel(InitParams P)
@@ -162,6 +188,11 @@ void launch_outer_update(const OuterParams &p, hipStream_t s)
 void launch_cost_history(const CostHistParams &p, hipStream_t s)
 {
     hipLaunchKernelGGL(cfs_cost_history_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
+}
+
+void launch_build_terms(const TermsParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(cfs_build_terms_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
 }
 
 void launch_init(const InitParams &p, hipStream_t s)

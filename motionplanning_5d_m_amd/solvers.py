@@ -138,6 +138,25 @@ class CFSBatch:
         _lib.check(self._lib.cfs_solve_batch_device(self._h, C.byref(i), C.byref(o), C.c_void_p(stream)))
         return out
 
+    # ---- per-problem setup on the device (row f2) ------------------------------------------------------
+    def set_state_cost(self, Qaug):
+        """The drivers' state-cost matrix Qaug (main_FANUC.m:79-84), once per handle."""
+        q = np.asfortranarray(Qaug, dtype=np.float64)
+        assert q.shape == (self.nx, self.nx)
+        _lib.check(self._lib.cfs_set_state_cost(self._h, _ptr(q)))
+
+    def build_terms_device(self, x0, xg, stream=None):
+        """(x_init, xR1, ff, caug) as CUDA tensors for B (start, goal) pairs given as CUDA tensors (B, njoint)."""
+        B = x0.shape[0]
+        assert x0.is_cuda and xg.is_cuda and x0.dtype == torch.float64 and x0.is_contiguous() and xg.is_contiguous()
+        z = lambda *sh: torch.empty(*sh, dtype=torch.float64, device=x0.device)  # noqa: E731
+        x_init, xR1, ff, caug = z(B, self.nx), z(B, self.ns), z(B, self.nn), z(B)
+        if stream is None:
+            stream = torch.cuda.current_stream(x0.device).cuda_stream
+        _lib.check(self._lib.cfs_build_terms_device(self._h, B, _ptr(x0), _ptr(xg), _ptr(x_init), _ptr(xR1), _ptr(ff), _ptr(caug),
+                                                    C.c_void_p(stream)))
+        return x_init, xR1, ff, caug
+
     # ---- measurement ------------------------------------------------------------------------------
     def profile(self, on=True):
         _lib.check(self._lib.cfs_profile_enable(self._h, 1 if on else 0))

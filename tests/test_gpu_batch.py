@@ -108,3 +108,24 @@ def test_config4_shape_h40_two_obstacles(gpu, O, route_wp):
     ok = same & (got.status < 2)
     err = np.abs(got.x_ - want.x_).max(axis=1)[ok]
     assert ok.sum() >= 32 and (err < 1e-5).mean() >= 0.9, np.sort(err)[-6:]
+
+
+def test_device_problem_builder_matches_host_builder(gpu, wl):
+    # row f2: line reference + ff + caug for (start, goal) pairs on the device vs the host builder (main_FANUC.m:38-49, 98-103)
+    s, bt = wl
+    n = 200
+    slv = gpu.CFSBatch(s, bt.nobs, bt.margin_cfs, mode="CFS", max_batch=n)
+    slv.set_state_cost(s.Qaug_state)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()  # noqa: E731
+    x_init, xR1, ff, caug = slv.build_terms_device(t(bt.x0[:n]), t(bt.xg[:n]))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(x_init.cpu().numpy(), bt.x_init[:n], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(xR1.cpu().numpy(), bt.xR1[:n])
+    np.testing.assert_allclose(ff.cpu().numpy(), bt.ff[:n], rtol=1e-12, atol=1e-7)
+    np.testing.assert_allclose(caug.cpu().numpy(), bt.caug[:n], rtol=1e-12)
+    out = slv.solve_device(x_init, xR1, ff, caug, t(bt.obs[:n]))          # and the solve runs straight from them
+    torch.cuda.synchronize()
+    host = slv.solve(bt.x_init[:n], bt.xR1[:n], bt.ff[:n], bt.caug[:n], bt.obs[:n])
+    same = (out.status.cpu().numpy() == host.status) & (out.iter_O.cpu().numpy() == host.iter_O)
+    assert same.mean() > 0.98
