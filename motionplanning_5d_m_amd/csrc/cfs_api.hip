@@ -202,6 +202,8 @@ int cfs_set_device(int device)
     return CFS_SUCCESS;
 }
 
+static size_t pt_stride(int nn) { return nn > 160 ? (size_t)256 * 256 : (nn > 96 ? (size_t)160 * 160 : 8); }   // >= (QB-PR)*QB
+
 static int check_robot(const cfs_robot *r, int nj)
 {
     if (!r) return fail(CFS_ERR_INVALID_ARG, "robot is NULL");
@@ -335,7 +337,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
 #define A_(buf, count) if (e == hipSuccess) e = p->buf.alloc(count)
     A_(rb, 1); A_(QQ, (size_t)nn * nn); A_(Hinv, (size_t)nn * nn); A_(M1, (size_t)nn * nn); A_(M2, (size_t)nn * nn);
     for (int m = 0; m < 6; ++m) { A_(Mr[m], (size_t)nn * nn); }
-    A_(M3, (size_t)nn * nn); A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * 128 * 160); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
+    A_(M3, (size_t)nn * nn); A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * pt_stride(nn)); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
     A_(cost_new, Bm); A_(cost_old, Bm); A_(delta, Bm); A_(e_u, Bm); A_(Yg, Bm * nn * nn); A_(Tg, Bm * nn * nn);
     if (desc->mode == CFS_MODE_CFS) { A_(u_hist, Bm * (size_t)desc->MAX_O_ITER * nn); A_(qu_hist, Bm * (size_t)desc->MAX_O_ITER * nn); }
@@ -414,7 +416,7 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     fp.x0 = p->x0.p;
     fp.u = out->u; fp.x_ = out->x_; fp.cost_all = out->cost_all; fp.e_cost_all = out->e_cost_all; fp.e_u_all = out->e_u_all;
     fp.iter_O = out->iter_O; fp.total_iter = out->total_iter; fp.status = out->status;
-    fp.Yg = p->Yg.p; fp.Pt = p->Pt.p;
+    fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(nn);
     fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
     fp.stamps = (g_stamps && B <= g_stamps_B) ? g_stamps : nullptr;
     fp.u_hist = (p->d.mode == CFS_MODE_CFS && K > 0) ? p->u_hist.p : nullptr;

@@ -139,7 +139,8 @@ struct FusedParams {
     double *u, *x_, *cost_all, *e_cost_all, *e_u_all;
     int *iter_O, *total_iter, *status;
     double *Yg;                  // B x nn x nn: Y rows beyond the LDS capacity
-    double *Pt;                  // B x 64 x 160: columns of the inverse Gram matrix beyond the register-resident 96
+    double *Pt;                  // B x pt_stride: columns of the inverse Gram matrix beyond the register-resident ones
+    size_t pt_stride;
     double *dbg;                 // optional trace: 8 doubles per active-set step of problem dbg_b (developer aid)
     int dbg_b, dbg_cap;
     unsigned long long *stamps;  // optional: 16 cycle accumulators per problem (developer aid)

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     double *red = lds + L.red;
     double *s_lim = lds + L.small, *s_v0 = s_lim + NJ, *s_th0 = s_v0 + NJ, *s_margin = s_th0 + 2 * NJ;
     double *s_mx = lds + L.mx;
-    double *s_pt = P.Pt + (size_t)b * (QB - PR) * QB;   // columns [PR,QB) of P, [b-PR][a]
+    double *s_pt = P.Pt + (size_t)b * P.pt_stride;        // columns [PR,QB) of P, [b-PR][a]
     double *s_Y = lds + L.y;                        // QY rows of HN doubles; linearisation scratch in between
     const int QY = P.qy;
     double *Yg = P.Yg + (size_t)b * nn * nn;
@@ -790,7 +790,7 @@ hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
 bool fused_fits(int nj, int H, int nobs)
 {
     const int nn = H * nj;
-    const int QB = nn <= 96 ? 96 : 160;
+    const int QB = nn <= 96 ? 96 : (nn <= 160 ? 160 : 256);
     const FusedLayout L = fused_layout(nj, H, nobs, QB, QB < CFS_PR ? QB : CFS_PR);
     const size_t avail = (160 * 1024 / CFS_WG_PER_CU) / 8 - 64;
     const size_t per_wp = (size_t)nj * 7 + (size_t)nvt(nj) * (18 + nobs);
@@ -801,7 +801,7 @@ bool fused_fits(int nj, int H, int nobs)
 hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
 {
     const int nn = p.H * nj;
-    const int QB = nn <= 96 ? 96 : 160;
+    const int QB = nn <= 96 ? 96 : (nn <= 160 ? 160 : 256);
     const FusedLayout L = fused_layout(nj, p.H, p.nobs, QB, QB < CFS_PR ? QB : CFS_PR);
     const size_t avail = (160 * 1024 / CFS_WG_PER_CU) / 8 - 64;   // doubles per workgroup, small safety margin
     if ((size_t)L.total_fixed + 4 * nn > avail) return hipErrorInvalidValue;
@@ -826,6 +826,9 @@ hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
     case 5160: return launch_fused_inst<5, 160>(p, lds, s);
     case 6160: return launch_fused_inst<6, 160>(p, lds, s);
     case 3160: return launch_fused_inst<3, 160>(p, lds, s);
+    case 4256: return launch_fused_inst<4, 256>(p, lds, s);
+    case 5256: return launch_fused_inst<5, 256>(p, lds, s);
+    case 6256: return launch_fused_inst<6, 256>(p, lds, s);
     default: return hipErrorInvalidValue;
     }
 }

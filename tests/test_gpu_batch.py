@@ -129,3 +129,14 @@ def test_device_problem_builder_matches_host_builder(gpu, wl):
     host = slv.solve(bt.x_init[:n], bt.xR1[:n], bt.ff[:n], bt.caug[:n], bt.obs[:n])
     same = (out.status.cpu().numpy() == host.status) & (out.iter_O.cpu().numpy() == host.iter_O)
     assert same.mean() > 0.98
+
+
+def test_capacity_beyond_160_rows_h40(gpu, O, route_wp):
+    # nn = 200: an infeasibility proof may need more than 160 active rows; the 256-row instantiation keeps it exact
+    s, bt = workloads.config4(route_wp, B=96, seed=11, sigma=0.05)
+    slv = gpu.CFSBatch(s, 2, bt.margin_cfs, mode="CFS", max_batch=96)
+    got = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs)
+    want = O.optimizer_batch(O.robotproperty2("M200i"), "CFS", 40, 5, bt.x_init, bt.xR1, s.QQ, bt.ff, bt.caug, s.Aaug, s.Baug, s.lim,
+                             s.MAX_input, bt.obs, bt.margin_cfs, s.epsilon_O, s.MAX_O_ITER, s.alpha, nthreads=0)
+    assert (got.status != 3).all(), np.bincount(got.status, minlength=4)
+    assert ((got.status == 2) == (want.status == 2)).mean() >= 0.95
