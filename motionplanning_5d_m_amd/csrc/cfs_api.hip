@@ -131,6 +131,7 @@ struct cfs_problem {
     cfs_problem_desc d;
     int device;
     int nn, ns, nx;
+    double lmax_vel;
     DevRobot hrobot;
     DevBuf<DevRobot> rb;
     DevBuf<double> QQ, Hinv, Hq, M1, M2, M3, M1n, M2n, lim, maxin, margin;
@@ -305,6 +306,37 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
             }
     }
 
+    // rigorous upper bound of lambda_max(G), G = D'HqD/dt^2 (D = first difference along the waypoints, so that
+    // u = D s/dt for s = Bvel u): lambda_max(G) <= ||G^(2^k)||_inf^(1/2^k); five squarings are within n^(1/32) of it
+    double lmax_vel = 0.0;
+    {
+        std::vector<double> Hs((size_t)nn * nn), G((size_t)nn * nn), T2((size_t)nn * nn);
+        for (int j = 0; j < nn; ++j)
+            for (int i = 0; i < nn; ++i)
+                Hs[i + (size_t)j * nn] = desc->mode == CFS_MODE_CFS ? 0.5 * ((double)desc->QQ[i + (size_t)j * nn] + desc->QQ[j + (size_t)i * nn]) : (i == j ? 1.0 : 0.0);
+        auto Dt = [&](std::vector<double> &M, bool left) {     // M <- D'M (left) or M D (right): row/col k minus row/col k+nj
+            for (int o = 0; o < nn; ++o)
+                for (int k = 0; k + nj < nn; ++k) {
+                    if (left) M[k + (size_t)o * nn] -= M[(k + nj) + (size_t)o * nn];
+                    else M[o + (size_t)k * nn] -= M[o + (size_t)(k + nj) * nn];
+                }
+        };
+        G = Hs; Dt(G, true); Dt(G, false);
+        for (auto &v : G) v /= (double)(dt * dt);
+        double logscale = 0.0;
+        for (int it = 0; it < 5; ++it) {
+            double nrm = 0.0;
+            for (int i = 0; i < nn; ++i) { double s = 0.0; for (int j = 0; j < nn; ++j) s += fabs(G[i + (size_t)j * nn]); if (s > nrm) nrm = s; }
+            for (auto &v : G) v /= nrm;
+            logscale = 2.0 * (logscale + log(nrm));
+            for (int i = 0; i < nn; ++i)
+                for (int j = 0; j < nn; ++j) { double s = 0.0; for (int k = 0; k < nn; ++k) s += G[i + (size_t)k * nn] * G[k + (size_t)j * nn]; T2[i + (size_t)j * nn] = s; }
+            G.swap(T2);
+        }
+        double nrm = 0.0;
+        for (int i = 0; i < nn; ++i) { double s = 0.0; for (int j = 0; j < nn; ++j) s += fabs(G[i + (size_t)j * nn]); if (s > nrm) nrm = s; }
+        lmax_vel = exp((logscale + log(nrm)) / 32.0) * 1.001;   // + margin for the fp64 rounding of the squarings
+    }
     // rollouts of every family column (double integrator: Bvel w = dt*cumsum(w), Bpos w = sum (i-k+1/2) dt^2 w_k)
     std::vector<double> Mroll[6];
     {
@@ -330,7 +362,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     p->d = *desc;
     p->d.QQ = p->d.Aaug = p->d.Baug = p->d.lim = p->d.MAX_input = p->d.margin = nullptr;
     p->device = g_device;
-    p->nn = nn; p->ns = ns; p->nx = nx;
+    p->nn = nn; p->ns = ns; p->nx = nx; p->lmax_vel = lmax_vel;
     build_dev_robot(desc->robot, p->hrobot);
     const size_t Bm = (size_t)desc->max_batch;
     hipError_t e = hipSetDevice(p->device);
@@ -408,7 +440,7 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     memset(&fp, 0, sizeof fp);
     fp.rb = p->rb.p; fp.B = B; fp.H = p->d.H; fp.nobs = p->d.nobs; fp.mode = p->d.mode;
     fp.has_bounds = p->d.mode == CFS_MODE_CFS; fp.max_o_iter = K; fp.noise_rows = in->noise ? in->noise_rows : 0;
-    fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O;
+    fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O; fp.lmax_vel = p->lmax_vel;
     fp.M1 = p->M1n.p; fp.M2 = p->M2n.p; fp.M3 = p->Hq.p; fp.QQ = p->QQ.p;
     fp.M1v = p->Mr[0].p; fp.M1p = p->Mr[1].p; fp.M2v = p->Mr[2].p; fp.M2p = p->Mr[3].p; fp.M3v = p->Mr[4].p; fp.M3p = p->Mr[5].p;
     fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
