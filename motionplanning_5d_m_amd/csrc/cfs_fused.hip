@@ -30,6 +30,9 @@ namespace {
 #ifndef CFS_WG_PER_CU
 #define CFS_WG_PER_CU 1                   // workgroups resident per CU (2: half the LDS and registers each)
 #endif
+#ifndef CFS_ANGLE_ADD
+#define CFS_ANGLE_ADD 0                    // 1: sin/cos of theta +- eps/2 by angle addition (measured: no faster, and the 1e-16 differences it seeds cost parity on the chaotic minority)
+#endif
 #ifndef CFS_PR
 #define CFS_PR 64                        // columns of each inverse-Gram row kept in registers
 #endif
@@ -363,13 +366,23 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         // =========================================================================================
         {
             const int W = P.lin_w;
-            double *s_th = s_Y;                              // [W][NJ]
-            double *s_sc = s_th + W * NJ;                    // [W][NJ][3][2]
-            double *s_tm = s_sc + W * NJ * 6;                // [W][NVT][12]
-            double *s_en = s_tm + W * NVT * 12;              // [W][NVT][6]
+            double *s_sc = s_Y;                              // [W][NJ][3][2] sin, cos of theta, theta+eps/2, theta-eps/2 (minus the joint offset)
+            double *s_en = s_sc + W * NJ * 6;                // [W][NVT][6]  capsule end points of every link variant
             double *s_dt = s_en + W * NVT * 6;               // [W][NVT][nobs]
+            const double ch = cos(FD_EPS / 2), sh = sin(FD_EPS / 2);
             for (int w0 = 0; w0 < H; w0 += W) {
                 const int Wc = min(W, H - w0);
+#if CFS_ANGLE_ADD
+                for (int e = tid; e < Wc * NJ; e += FT) {
+                    const int m = e % NJ, wi = e / NJ;
+                    double sn, cs;
+                    sincos(s_x[(w0 + wi) * NS + m] - rb->th_off[m], &sn, &cs);   // dist_arm_3D_200i_2.m:11
+                    s_sc[e * 6] = sn;
+                    s_sc[e * 6 + 1] = cs;
+                    s_sc[e * 6 + 2] = sn * ch + cs * sh; s_sc[e * 6 + 3] = cs * ch - sn * sh;
+                    s_sc[e * 6 + 4] = sn * ch - cs * sh; s_sc[e * 6 + 5] = cs * ch + sn * sh;
+                }
+#else
                 for (int e = tid; e < Wc * NJ * 3; e += FT) {
                     const int var = e % 3, m = (e / 3) % NJ, wi = e / (3 * NJ);
                     double x = s_x[(w0 + wi) * NS + m];
@@ -378,36 +391,41 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     x = x - rb->th_off[m];                   // dist_arm_3D_200i_2.m:11
                     double sn, cs;
                     sincos(x, &sn, &cs);
-                    s_sc[((wi * NJ + m) * 3 + var) * 2 + 0] = sn;
+                    s_sc[((wi * NJ + m) * 3 + var) * 2] = sn;
                     s_sc[((wi * NJ + m) * 3 + var) * 2 + 1] = cs;
                 }
+#endif
                 __syncthreads();
-                for (int k1 = 1; k1 <= NJ; ++k1) {
-                    const int nv = 2 * k1 + 1;
-                    for (int e = tid; e < Wc * nv; e += FT) {
-                        const int v = e % nv, wi = e / nv;
-                        const int avar = (v == 2 * k1 - 1) ? 1 : (v == 2 * k1 ? 2 : 0);
-                        const int pv = min(v, 2 * (k1 - 1));
-                        const double sn = s_sc[((wi * NJ + (k1 - 1)) * 3 + avar) * 2 + 0];
-                        const double cs = s_sc[((wi * NJ + (k1 - 1)) * 3 + avar) * 2 + 1];
-                        const double *par = (k1 == 1) ? nullptr : s_tm + (wi * NVT + kvoff(k1 - 1) + pv) * 12;
-                        double M[12], e6[6];
-                        fk_step(rb, k1 - 1, sn, cs, par, M);
-                        link_ends(rb, k1 - 1, M, e6);
-                        double *dstM = s_tm + (wi * NVT + kvoff(k1) + v) * 12;
-                        double *dstE = s_en + (wi * NVT + kvoff(k1) + v) * 6;
+                // one thread per (waypoint, evaluation point of num_jac): the whole kinematic chain in registers.
+                // Evaluation point ev has joint m at +eps/2 if ev == 2m-1, at -eps/2 if ev >= 2m (num_jac.m:8-14:
+                // xp is never restored); the shifted sin/cos come from the base pair by angle addition.  Link k of
+                // evaluation ev is variant min(ev, 2k); the thread with ev <= 2k is the one that stores it.
+                for (int e = tid; e < Wc * NE; e += FT) {
+                    const int ev = e % NE, wi = e / NE;
+                    double M[12], Mn[12], e6[6];
 #pragma unroll
-                        for (int qq = 0; qq < 12; ++qq) dstM[qq] = M[qq];
+                    for (int k1 = 1; k1 <= NJ; ++k1) {
+                        const int avar = (ev == 2 * k1 - 1) ? 1 : (ev >= 2 * k1 ? 2 : 0);
+                        const double sn = s_sc[((wi * NJ + k1 - 1) * 3 + avar) * 2], cs = s_sc[((wi * NJ + k1 - 1) * 3 + avar) * 2 + 1];
+                        fk_step(rb, k1 - 1, sn, cs, k1 == 1 ? nullptr : M, Mn);
 #pragma unroll
-                        for (int qq = 0; qq < 6; ++qq) dstE[qq] = e6[qq];
+                        for (int qq = 0; qq < 12; ++qq) M[qq] = Mn[qq];
+                        if (ev <= 2 * k1) {
+                            link_ends(rb, k1 - 1, M, e6);
+                            double *dstE = s_en + (wi * NVT + kvoff(k1) + ev) * 6;
+#pragma unroll
+                            for (int qq = 0; qq < 6; ++qq) dstE[qq] = e6[qq];
+                        }
                     }
-                    __syncthreads();
                 }
+                __syncthreads();
+                STAMP(10);                                  // 10: sincos + link transforms
                 for (int e = tid; e < NVT * Wc * nobs; e += FT) {
                     const int j = e % nobs, wi = (e / nobs) % Wc, kv = e / (nobs * Wc);
                     s_dt[(wi * NVT + kv) * nobs + j] = seg_seg_dist(s_en + (wi * NVT + kv) * 6, s_ob + j * 6);
                 }
                 __syncthreads();
+                STAMP(11);                                  // 11: segment pairs
                 for (int e = tid; e < Wc * nobs; e += FT) {
                     const int j = e % nobs, wi = e / nobs;
                     const double *tab = s_dt + (wi * NVT) * nobs + j;
@@ -745,9 +763,12 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             for (int k = tid; k < HN; k += FT) {
                 double sa[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                 int c = 0;
-                for (; c + 8 <= HN; c += 8) {                   // 8 independent L2 loads in flight per thread
+                for (; c + 16 <= HN; c += 16) {                 // 16 independent L2 loads in flight per thread
+                    double ld[16];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sa[j] += P.QQ[k + (size_t)(c + j) * nn] * s_u[c + j];
+                    for (int j = 0; j < 16; ++j) ld[j] = P.QQ[k + (size_t)(c + j) * nn];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sa[j & 7] += ld[j] * s_u[c + j];
                 }
                 for (; c < HN; ++c) sa[0] += P.QQ[k + (size_t)c * nn] * s_u[c];
                 const double s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
@@ -800,7 +821,7 @@ bool fused_fits(int nj, int H, int nobs)
     const int QB = nn <= 96 ? 96 : (nn <= 160 ? 160 : 256);
     const FusedLayout L = fused_layout(nj, H, nobs, QB, QB < CFS_PR ? QB : CFS_PR);
     const size_t avail = (160 * 1024 / CFS_WG_PER_CU) / 8 - 64;
-    const size_t per_wp = (size_t)nj * 7 + (size_t)nvt(nj) * (18 + nobs);
+    const size_t per_wp = (size_t)nj * 6 + (size_t)nvt(nj) * (6 + nobs);
     return (size_t)L.total_fixed + std::max((size_t)4 * nn, per_wp) <= avail;
 }
 
@@ -816,7 +837,7 @@ hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
     int qy = (int)(region / nn);
     if (qy > nn) qy = nn;
     const int NVT = nvt(nj);
-    const size_t per_wp = (size_t)nj * 7 + (size_t)NVT * (18 + p.nobs);
+    const size_t per_wp = (size_t)nj * 6 + (size_t)NVT * (6 + p.nobs);
     int w = (int)(region / per_wp);
     if (w > p.H) w = p.H;
     if (w < 1) return hipErrorInvalidValue;

@@ -53,6 +53,24 @@ __device__ __forceinline__ void link_ends(const DevRobot *rb, int k, const doubl
     }
 }
 
+// a/b without the IEEE special-case scaffolding (v_div_scale/fmas/fixup): v_rcp_f64 seed, two Newton
+// steps, one residual correction.  Result within 1 ulp of the correctly rounded quotient for the finite,
+// well-scaled operands of this routine (lengths and dot products of link / obstacle axes in metres).
+#ifndef CFS_FAST_DIV
+#define CFS_FAST_DIV 1
+#endif
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+#if !CFS_FAST_DIV
+    return a / b;
+#endif
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
 __device__ __forceinline__ double fixbound(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
 // distLinSeg.m:23-91 followed by the near-zero surrogate of dist_arm_3D_200i_2.m:22-24.
@@ -70,19 +88,19 @@ __device__ __forceinline__ double seg_seg_dist(const double *a6, const double *o
     const double den = D1 * D2 - R * R;
     double t, u;
     if (D1 == 0.0 || D2 == 0.0) {
-        if (D1 != 0.0) { u = 0.0; t = fixbound(S1 / D1); }
-        else if (D2 != 0.0) { t = 0.0; u = fixbound(-S2 / D2); }
+        if (D1 != 0.0) { u = 0.0; t = fixbound(fdiv(S1, D1)); }
+        else if (D2 != 0.0) { t = 0.0; u = fixbound(fdiv(-S2, D2)); }
         else { t = 0.0; u = 0.0; }
     } else if (den == 0.0) {
         t = 0.0;
-        u = -S2 / D2;
+        u = fdiv(-S2, D2);
         const double uf = fixbound(u);
-        if (uf != u) { t = fixbound((uf * R + S1) / D1); u = uf; }
+        if (uf != u) { t = fixbound(fdiv(uf * R + S1, D1)); u = uf; }
     } else {
-        t = fixbound((S1 * D2 - S2 * R) / den);
-        u = (t * R - S2) / D2;
+        t = fixbound(fdiv(S1 * D2 - S2 * R, den));
+        u = fdiv(t * R - S2, D2);
         const double uf = fixbound(u);
-        if (uf != u) { t = fixbound((uf * R + S1) / D1); u = uf; }
+        if (uf != u) { t = fixbound(fdiv(uf * R + S1, D1)); u = uf; }
     }
     const double ex = d1x * t - d2x * u - d12x, ey = d1y * t - d2y * u - d12y, ez = d1z * t - d2z * u - d12z;
     double dis = sqrt(ex * ex + ey * ey + ez * ez);

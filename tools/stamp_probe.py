@@ -15,13 +15,13 @@ r = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs, noise=bt.noise if mode 
 st = np.zeros((B, 12), np.uint64)
 lib.cfs_debug_stamps(B, st.ctypes.data_as(C.c_void_p))
 st = st.astype(np.float64)
-names = ["linearise", "qp setup", "step1 scan", "w gather+roll", "d, r=Pd", "z+roll+refine", "steplen/update", "add", "drop", "post (roll,cost)"]
+names = ["lin: minima+FD", "qp setup", "step1 scan", "w gather+roll", "d, r=Pd", "z+roll+refine", "steplen/update", "add", "drop", "post (roll,cost)", "lin: sincos+FK", "lin: segment pairs"]
 tot = st.sum(axis=1)
 its = r.iter_O - 1; steps = r.total_iter
 print("clock64 ticks are 100 MHz (s_memtime = constant clock): 1 tick = 10 ns")
 for grp, m in (("all", np.ones(B, bool)), ("solved", r.status < 2), ("infeasible", r.status == 2)):
     t = st[m].sum(axis=0)
-    print(f"[{grp}] problems {m.sum()}, outer its {its[m].sum()}, QP steps {steps[m].sum()}, total {t.sum()*1e-2/1e3:.1f} ms of WG time; per step {t[2:9].sum()*10/max(steps[m].sum(),1)/1e3:.2f} us; per-iteration linearise {t[0]*10/max((its[m]+ (r.status[m]==2)).sum(),1)/1e3:.2f} us, post {t[9]*10/max(its[m].sum(),1)/1e3:.2f} us")
+    print(f"[{grp}] problems {m.sum()}, outer its {its[m].sum()}, QP steps {steps[m].sum()}, total {t.sum()*1e-2/1e3:.1f} ms of WG time; per step {t[2:9].sum()*10/max(steps[m].sum(),1)/1e3:.2f} us; per-iteration linearise {(t[0]+t[10]+t[11])*10/max((its[m]+ (r.status[m]==2)).sum(),1)/1e3:.2f} us, post {t[9]*10/max(its[m].sum(),1)/1e3:.2f} us")
     print("   " + ", ".join(f"{n} {100*v/t.sum():.1f}%" for n, v in zip(names, t)))
 worst = np.argsort(-tot)[:5]
 print("slowest problems:", [(int(b), int(r.status[b]), int(r.iter_O[b]), int(steps[b]), round(tot[b]*1e-5, 2)) for b in worst], "(b, status, iter_O, steps, ms)")
