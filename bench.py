@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete batched solve (all outer iterations, convergence-terminated, <= 20) of the
+One "step" = one complete batched solve (all outer iterations: 20 for PSGCFS_FANUC, the solver the batch-1024
+config of BASELINE.json names; convergence-terminated <= 20 for CFS_FANUC, reported under "other_mode") of the
 1024 problems resident on this rank's GPU; inputs are in HBM before the timed region starts.  One
 unit = one CFS outer iteration of one problem (get_con + QP + rollout + cost/stop test; BASELINE.md
 section 3).  With N GPUs every rank solves its own 1024 problems (weak scaling, seed + rank) and the
@@ -44,11 +45,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="CFS", choices=["CFS", "PSGCFS"])
+    ap.add_argument("--mode", default="PSGCFS", choices=["CFS", "PSGCFS"],
+                    help="headline solver: PSGCFS_FANUC is the solver BASELINE.json's batch-1024 config names; the other "
+                         "one is measured too (shorter) and reported under 'other_mode'")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=8,
                     help="independent solves in flight (one handle + HIP stream each); 1 = strictly serial steps")
+    ap.add_argument("--no-other-mode", action="store_true", help="measure only --mode (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,8 +69,26 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B, mode = args.batch, args.mode
+    B = args.batch
+    head = measure(args, args.mode, args.steps, args.warmup, world, rank, local, dev, backend, B, headline=True)
+    other = "CFS" if args.mode == "PSGCFS" else "PSGCFS"
+    oth = None
+    if not args.no_other_mode:
+        oth = measure(args, other, max(4, args.steps // 2), max(1, args.warmup // 2), world, rank, local, dev, backend, B, headline=False)
+    if rank == 0 and oth is None:
+        print(json.dumps(head), flush=True)
+    elif rank == 0:
+        head["other_mode"] = {k: oth[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
+        head["other_mode"]["config"] = {k: oth["config"][k] for k in ("solver", "iterations_per_step_rank0", "status_counts_rank0",
+                                                                        "concurrent_solves", "ms_single_solve_alone")}
+        head["other_mode"]["roofline"] = {k: oth["roofline"][k] for k in ("achieved", "frac", "kernel_ms_per_launch", "achieved_all_streams")}
+        print(json.dumps(head), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, headline):
     # ---- synthetic inputs, generated with the GPU distance entry point, then resident in HBM
     pkg.lib().cfs_set_device(local)
     s, bt = workloads.config3(lambda rb, th, ob: pkg.dist_arm(rb, th, ob)[0], B=B, seed=20260101 + rank)
@@ -102,7 +124,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(max(args.warmup, 1)):
+    for i in range(max(warmup, 1)):
         step(i)
     fence()
     # latency of one solve alone (stream 0, nothing else in flight)
@@ -113,7 +135,7 @@ def main():
     for sl in slvs:
         sl.profile(True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     fence()
     dt = time.perf_counter() - t0
@@ -147,10 +169,10 @@ def main():
                 traffic = None
         res = {
             "metric": "CFS iterations/sec, 5-DoF 30-wp 8-obs batch-1024; l_inf wp err vs quadprog",
-            "value": units_all * args.steps / dt_max,
+            "value": units_all * steps / dt_max,
             "unit": "CFS iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt_max / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config3: M200i 5-DoF, H=30, 8 vertical line obstacles, batch %d per GPU, %s (%s), "
@@ -165,17 +187,19 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms_per_launch": kern_ms, "gemm_ms_per_launch": gemm_ms / max(nsolves, 1),
                          "algorithmic_bytes_per_unit": ALGO_BYTES_PER_UNIT, "units_per_launch": units_step,
-                         "achieved_all_streams": ALGO_BYTES_PER_UNIT * units_step * args.steps / dt_max / 1e9,
+                         "achieved_all_streams": ALGO_BYTES_PER_UNIT * units_step * steps / dt_max / 1e9,
                          "note": "achieved = per-launch figure (launches of different steps overlap on %d streams; "
                                  "achieved_all_streams = bytes of all launches / wall time); true limiter is fp64 VALU + LDS "
                                  "latency of the sequential active-set steps, not HBM (DESIGN.md)" % S},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and headline and not args.no_cpu_baseline:
             res["cpu_baseline"], res["accuracy"] = cpu_baseline(s, bt, mode, margin, out)
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        for sl in slvs:
+            sl.close()
+        return res
+    for sl in slvs:
+        sl.close()
+    return None
 
 
 def cpu_baseline(s, bt, mode, margin, out):
