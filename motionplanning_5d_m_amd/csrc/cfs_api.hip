@@ -56,6 +56,19 @@ void build_dev_robot(const cfs_robot &r, DevRobot &d)
     if (r.kind == CFS_ROBOT_2L)
         for (int i = 0; i + 1 < 3 && i < CFS_MAX_LINKS; ++i)   // link i uses robot.T(:,i+2) (1-based), CapPos2.m:25
             for (int e = 0; e < 3; ++e) d.t2l[i * 3 + e] = r.T[(i + 1) * 3 + e];
+    // every point of the arm stays within `reach` of every joint axis; an evaluation point of num_jac moves each joint
+    // by at most eps/2, so no link-obstacle distance changes by more than nlink*eps/2*reach (the segment distance is
+    // 1-Lipschitz in the end points).  The pruning margin of the linearisation is a generous multiple of that.
+    double reach = 0.0, capmax = 0.0;
+    for (int i = 0; i < r.nlink && i < CFS_MAX_LINKS; ++i) {
+        reach += (r.kind == CFS_ROBOT_2L) ? sqrt(d.t2l[i * 3] * d.t2l[i * 3] + d.t2l[i * 3 + 1] * d.t2l[i * 3 + 1] + d.t2l[i * 3 + 2] * d.t2l[i * 3 + 2])
+                                          : fabs(d.dh_a[i]) + fabs(d.dh_d[i]);
+        for (int k = 0; k < 2; ++k) {
+            const double *c = d.cap + i * 6 + k * 3;
+            capmax = std::max(capmax, sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]));
+        }
+    }
+    d.prune_tol = 1e-3 + 8.0 * r.nlink * (1e-5 / 2) * (reach + capmax);
 }
 
 template <class T>
@@ -164,6 +177,20 @@ static int g_stamps_B = 0;
 static double *g_dbg = nullptr;
 static int g_dbg_b = -1, g_dbg_cap = 0;
 
+// Tier of the fused kernel (cfs_device.h).  Two problems per CU win whenever they fit: measured on config 3, PSGCFS
+// 3.6 -> 2.3 ms per solve with w2s, CFS 5.8 -> 5.6 ms with w2m (its infeasibility proofs run active sets of ~100 rows).
+// CFS_TIER=w1|w2m|w2s overrides (developer A/B).
+bool fused_fits(int nj, int H, int nobs) { return fused_fits_w1(nj, H, nobs); }
+hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
+{
+    static const char *force = getenv("CFS_TIER");
+    int tier = p.mode == CFS_MODE_PSGCFS ? 2 : 1;
+    if (force) tier = !strcmp(force, "w1") ? 0 : (!strcmp(force, "w2m") ? 1 : (!strcmp(force, "w2s") ? 2 : tier));
+    if (tier == 2 && fused_fits_w2s(nj, p.H, p.nobs)) return launch_fused_w2s(nj, p, s);
+    if (tier == 1 && fused_fits_w2m(nj, p.H, p.nobs)) return launch_fused_w2m(nj, p, s);
+    return launch_fused_w1(nj, p, s);
+}
+
 extern "C" {
 
 int cfs_debug_trace_begin(int b, int cap)
@@ -203,7 +230,8 @@ int cfs_set_device(int device)
     return CFS_SUCCESS;
 }
 
-static size_t pt_stride(int nn) { return nn > 160 ? (size_t)256 * 256 : (nn > 96 ? (size_t)160 * 160 : 8); }   // >= (QB-PR)*QB
+static size_t pt_stride(int nn) { return nn > 160 ? (size_t)256 * 256 : (nn > 96 ? (size_t)160 * 160 : (size_t)96 * 96); }   // QB*QB >= (QB-PR)*QB in every tier
+
 
 static int check_robot(const cfs_robot *r, int nj)
 {

@@ -20,6 +20,8 @@ struct DevRobot {
     double base[3];
     double cap[CFS_MAX_LINKS * 6];  // cap[i*6 + k*3 + r]
     double t2l[CFS_MAX_LINKS * 3];  // 2L: translation of link i = robot.T(:,i+1)  (CapPos2.m:25)
+    double prune_tol;               // a link farther than this from the base-pose minimum cannot become the minimum at any
+                                    // evaluation point of num_jac (bound on the motion of any arm point: nlink*eps/2*reach)
 };
 static_assert(sizeof(DevRobot) % 8 == 0, "DevRobot is copied to LDS as doubles");
 
@@ -148,7 +150,17 @@ struct FusedParams {
     int opt;                     // developer A/B switches (bit 0: gather w only and roll it on the fly)
     double *u_hist;              // CFS: B x max_o_iter x nn log of u per outer iteration (cost history computed afterwards)
 };
-hipError_t launch_fused(int nj, FusedParams p, hipStream_t s);
+// cfs_fused.hip is compiled into three tiers (workgroups per CU / register-resident columns of the inverse Gram matrix):
+//   w1  1 / 64  whole CU per problem: longest on-chip active sets
+//   w2m 2 / 32  two problems per CU hide each other's latencies; medium active sets stay in registers
+//   w2s 2 / 16  same, smallest register footprint (no spills): the projection QPs of PSGCFS have 2-3 active rows
+hipError_t launch_fused_w1(int nj, FusedParams p, hipStream_t s);
+hipError_t launch_fused_w2m(int nj, FusedParams p, hipStream_t s);
+hipError_t launch_fused_w2s(int nj, FusedParams p, hipStream_t s);
+bool fused_fits_w1(int nj, int H, int nobs);
+bool fused_fits_w2m(int nj, int H, int nobs);
+bool fused_fits_w2s(int nj, int H, int nobs);
+hipError_t launch_fused(int nj, FusedParams p, hipStream_t s);   // cfs_api.hip: tier by mode and capacity
 bool fused_fits(int nj, int H, int nobs);
 
 struct CostHistParams {          // EVAL.get_cost / store_result for a logged u history (CFS mode)

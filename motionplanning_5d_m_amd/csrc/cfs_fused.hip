@@ -36,6 +36,13 @@ namespace {
 #ifndef CFS_PR
 #define CFS_PR 64                        // columns of each inverse-Gram row kept in registers
 #endif
+// This file is compiled once per tier (Makefile): CFS_VARIANT names the exported launch_fused_<tier> / fused_fits_<tier>.
+#ifndef CFS_VARIANT
+#define CFS_VARIANT w1
+#endif
+#define CFS_CAT2(a, b) a##_##b
+#define CFS_CAT(a, b) CFS_CAT2(a, b)
+static_assert(CFS_PR % 8 == 0 && CFS_PR >= 8, "register-resident P columns come in chunks of 8");
 constexpr int FT = 256;                  // threads per workgroup
 constexpr double DEP_TOL_F = 1e-8;       // dependent if delta <= tol * n'H^{-1}n: above the eps*cond(H) noise floor of Y = H^{-1}N
 enum { CT_COL = 0, CT_VELP = 1, CT_VELM = 2, CT_BNDP = 3, CT_BNDM = 4 };
@@ -369,10 +376,12 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             double *s_sc = s_Y;                              // [W][NJ][3][2] sin, cos of theta, theta+eps/2, theta-eps/2 (minus the joint offset)
             double *s_en = s_sc + W * NJ * 6;                // [W][NVT][6]  capsule end points of every link variant
             double *s_dt = s_en + W * NVT * 6;               // [W][NVT][nobs]
-            const double ch = cos(FD_EPS / 2), sh = sin(FD_EPS / 2);
+            unsigned short *s_list = reinterpret_cast<unsigned short *>(s_dt + W * NVT * nobs);   // [NJ][W*nobs] (wi << 8 | obstacle)
+            int *s_cnt = s_free;                             // candidates per link (the QP's free-slot stack is idle here)
             for (int w0 = 0; w0 < H; w0 += W) {
                 const int Wc = min(W, H - w0);
 #if CFS_ANGLE_ADD
+                const double ch = cos(FD_EPS / 2), sh = sin(FD_EPS / 2);
                 for (int e = tid; e < Wc * NJ; e += FT) {
                     const int m = e % NJ, wi = e / NJ;
                     double sn, cs;
@@ -420,21 +429,62 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 }
                 __syncthreads();
                 STAMP(10);                                  // 10: sincos + link transforms
-                for (int e = tid; e < NVT * Wc * nobs; e += FT) {
-                    const int j = e % nobs, wi = (e / nobs) % Wc, kv = e / (nobs * Wc);
+                // Base-pose distance of every link (dist_arm_3D_200i_2.m:16-26), link index slow so the point /
+                // segment branch of distLinSeg is wave-uniform.
+                for (int e = tid; e < NJ * Wc * nobs; e += FT) {
+                    const int j = e % nobs, wi = (e / nobs) % Wc, kv = kvoff(e / (nobs * Wc) + 1);
                     s_dt[(wi * NVT + kv) * nobs + j] = seg_seg_dist(s_en + (wi * NVT + kv) * 6, s_ob + j * 6);
+                }
+                if (tid < NJ) s_cnt[tid] = 0;
+                __syncthreads();
+                // num_jac only needs min over the links at 2nj shifted poses.  A link whose base distance exceeds
+                // max(min, 1e-4) by prune_tol can neither become the minimum nor reach the near-zero surrogate at any
+                // of them (see DevRobot::prune_tol), so only the other links are evaluated there: same minima, bit for bit.
+                for (int e = tid; e < Wc * nobs; e += FT) {
+                    const int j = e % nobs, wi = e / nobs;
+                    const double *tab = s_dt + (wi * NVT) * nobs + j;
+                    double bk[NJ], m0 = INFINITY;
+#pragma unroll
+                    for (int k1 = 1; k1 <= NJ; ++k1) { bk[k1 - 1] = tab[kvoff(k1) * nobs]; if (bk[k1 - 1] < m0) m0 = bk[k1 - 1]; }
+                    const double thr = fmax(m0, 0.0001) + rb->prune_tol;
+#pragma unroll
+                    for (int k1 = 1; k1 <= NJ; ++k1)
+                        if (bk[k1 - 1] < thr) s_list[(k1 - 1) * W * nobs + atomicAdd(&s_cnt[k1 - 1], 1)] = (unsigned short)((wi << 8) | j);
+                }
+                __syncthreads();
+                {
+                    int offs[NJ + 1];
+                    offs[0] = 0;
+#pragma unroll
+                    for (int k1 = 1; k1 <= NJ; ++k1) offs[k1] = offs[k1 - 1] + s_cnt[k1 - 1] * 2 * k1;
+                    for (int e = tid; e < offs[NJ]; e += FT) {
+                        int k1 = 1, ent = 0, v = 1;
+#pragma unroll
+                        for (int kk = 1; kk <= NJ; ++kk)
+                            if (e >= offs[kk - 1] && e < offs[kk]) {
+                                const int r_ = e - offs[kk - 1];
+                                k1 = kk; ent = r_ / (2 * kk); v = r_ - ent * (2 * kk) + 1;
+                            }
+                        const int item = s_list[(k1 - 1) * W * nobs + ent], wi = item >> 8, j = item & 255;
+                        const int kv = kvoff(k1) + v;
+                        s_dt[(wi * NVT + kv) * nobs + j] = seg_seg_dist(s_en + (wi * NVT + kv) * 6, s_ob + j * 6);
+                    }
                 }
                 __syncthreads();
                 STAMP(11);                                  // 11: segment pairs
                 for (int e = tid; e < Wc * nobs; e += FT) {
                     const int j = e % nobs, wi = e / nobs;
                     const double *tab = s_dt + (wi * NVT) * nobs + j;
-                    double dev[NE];
+                    double dev[NE], m0 = INFINITY;
+#pragma unroll
+                    for (int k1 = 1; k1 <= NJ; ++k1) m0 = fmin(m0, tab[kvoff(k1) * nobs]);
+                    const double thr = fmax(m0, 0.0001) + rb->prune_tol;
 #pragma unroll
                     for (int ev = 0; ev < NE; ++ev) {
                         double d = INFINITY;
 #pragma unroll
                         for (int k1 = 1; k1 <= NJ; ++k1) {
+                            if (!(tab[kvoff(k1) * nobs] < thr)) continue;
                             const double dis = tab[(kvoff(k1) + min(ev, 2 * k1)) * nobs];
                             if (dis < d) d = dis;
                         }
@@ -814,19 +864,25 @@ hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
 
 }  // namespace
 
+// linearisation scratch per waypoint of a tile: sin/cos, link end points, distance table, candidate lists (ushort)
+static size_t lin_doubles_per_wp(int nj, int nobs)
+{
+    return (size_t)nj * 6 + (size_t)nvt(nj) * (6 + nobs) + ((size_t)nj * nobs + 3) / 4;
+}
+
 // does the fused kernel's fixed LDS footprint (+ a minimal Y / linearisation region) fit a CU?
-bool fused_fits(int nj, int H, int nobs)
+bool CFS_CAT(fused_fits, CFS_VARIANT)(int nj, int H, int nobs)
 {
     const int nn = H * nj;
     const int QB = nn <= 96 ? 96 : (nn <= 160 ? 160 : 256);
     const FusedLayout L = fused_layout(nj, H, nobs, QB, QB < CFS_PR ? QB : CFS_PR);
     const size_t avail = (160 * 1024 / CFS_WG_PER_CU) / 8 - 64;
-    const size_t per_wp = (size_t)nj * 6 + (size_t)nvt(nj) * (6 + nobs);
+    const size_t per_wp = lin_doubles_per_wp(nj, nobs);
     return (size_t)L.total_fixed + std::max((size_t)4 * nn, per_wp) <= avail;
 }
 
 // host: choose the capacities, fill qy / lin_w, launch
-hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
+hipError_t CFS_CAT(launch_fused, CFS_VARIANT)(int nj, FusedParams p, hipStream_t s)
 {
     const int nn = p.H * nj;
     const int QB = nn <= 96 ? 96 : (nn <= 160 ? 160 : 256);
@@ -836,8 +892,7 @@ hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
     const size_t region = avail - L.total_fixed;
     int qy = (int)(region / nn);
     if (qy > nn) qy = nn;
-    const int NVT = nvt(nj);
-    const size_t per_wp = (size_t)nj * 6 + (size_t)NVT * (6 + p.nobs);
+    const size_t per_wp = lin_doubles_per_wp(nj, p.nobs);
     int w = (int)(region / per_wp);
     if (w > p.H) w = p.H;
     if (w < 1) return hipErrorInvalidValue;
