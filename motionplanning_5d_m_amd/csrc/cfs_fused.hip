@@ -261,7 +261,7 @@ struct PRow {
 };
 
 struct FusedLayout {      // LDS offsets in doubles, computed identically on host and device
-    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, code, red, small, mx, ptail, y, total_fixed;
+    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, code, red, small, mx, ptail, lin, y, total_fixed;
 };
 __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int QB, int PR)
 {
@@ -276,13 +276,6 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.g = o; o += nobs * HN;
     L.rhs = o; o += nobs * H;
     L.xs = o; o += 3 * HN;
-    L.wb = o; o += 3 * HN;
-    L.zb = o; o += 3 * HN;
-    L.d = o; o += QB;
-    L.r = o; o += QB;
-    L.rho = o; o += QB;
-    L.lam = o; o += QB;
-    L.prow = o; o += QB;
     L.act = o; o += (QB + 1) / 2;
     L.fre = o; o += (QB + 1) / 2;          // stack of freed slots
     L.flag = o; o += (nobs * H + 4 * HN + 7) / 8;
@@ -290,6 +283,15 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.red = o; o += 32;
     L.small = o; o += 4 * NJ + nobs;       // lim, v0, theta0 (2NJ), margin
     L.mx = o; o += HN;                     // MAX_input
+    o = (o + 1) & ~1;
+    L.lin = o;                             // linearisation scratch starts here: it may overwrite the QP's work vectors below
+    L.wb = o; o += 3 * HN;
+    L.zb = o; o += 3 * HN;
+    L.d = o; o += QB;
+    L.r = o; o += QB;
+    L.rho = o; o += QB;
+    L.lam = o; o += QB;
+    L.prow = o; o += QB;
     L.ptail = o;                           // (tail columns of P live in global scratch)
     o = (o + 1) & ~1;
     L.y = o;
@@ -373,10 +375,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         // =========================================================================================
         {
             const int W = P.lin_w;
-            double *s_sc = s_Y;                              // [W][NJ][3][2] sin, cos of theta, theta+eps/2, theta-eps/2 (minus the joint offset)
+            double *s_sc = lds + L.lin;                      // [W][NJ][3][2] sin, cos of theta, theta+eps/2, theta-eps/2 (minus the joint offset)
             double *s_en = s_sc + W * NJ * 6;                // [W][NVT][6]  capsule end points of every link variant
-            double *s_dt = s_en + W * NVT * 6;               // [W][NVT][nobs]
-            unsigned short *s_list = reinterpret_cast<unsigned short *>(s_dt + W * NVT * nobs);   // [NJ][W*nobs] (wi << 8 | obstacle)
+            double *s_bd = s_en + W * NVT * 6;               // [W][NJ][nobs] base-pose distance of every link
+            double *s_dv = s_bd + W * NJ * nobs;             // [W][nobs][NE] min over the links at every evaluation point of num_jac
+            unsigned short *s_list = reinterpret_cast<unsigned short *>(s_dv + W * nobs * NE);    // [NJ][W*nobs] (wi << 8 | obstacle)
             int *s_cnt = s_free;                             // candidates per link (the QP's free-slot stack is idle here)
             for (int w0 = 0; w0 < H; w0 += W) {
                 const int Wc = min(W, H - w0);
@@ -432,8 +435,8 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 // Base-pose distance of every link (dist_arm_3D_200i_2.m:16-26), link index slow so the point /
                 // segment branch of distLinSeg is wave-uniform.
                 for (int e = tid; e < NJ * Wc * nobs; e += FT) {
-                    const int j = e % nobs, wi = (e / nobs) % Wc, kv = kvoff(e / (nobs * Wc) + 1);
-                    s_dt[(wi * NVT + kv) * nobs + j] = seg_seg_dist(s_en + (wi * NVT + kv) * 6, s_ob + j * 6);
+                    const int j = e % nobs, wi = (e / nobs) % Wc, k0 = e / (nobs * Wc);
+                    s_bd[(wi * NJ + k0) * nobs + j] = seg_seg_dist(s_en + (wi * NVT + kvoff(k0 + 1)) * 6, s_ob + j * 6);
                 }
                 if (tid < NJ) s_cnt[tid] = 0;
                 __syncthreads();
@@ -442,14 +445,16 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 // of them (see DevRobot::prune_tol), so only the other links are evaluated there: same minima, bit for bit.
                 for (int e = tid; e < Wc * nobs; e += FT) {
                     const int j = e % nobs, wi = e / nobs;
-                    const double *tab = s_dt + (wi * NVT) * nobs + j;
                     double bk[NJ], m0 = INFINITY;
 #pragma unroll
-                    for (int k1 = 1; k1 <= NJ; ++k1) { bk[k1 - 1] = tab[kvoff(k1) * nobs]; if (bk[k1 - 1] < m0) m0 = bk[k1 - 1]; }
+                    for (int k1 = 1; k1 <= NJ; ++k1) { bk[k1 - 1] = s_bd[(wi * NJ + k1 - 1) * nobs + j]; if (bk[k1 - 1] < m0) m0 = bk[k1 - 1]; }
                     const double thr = fmax(m0, 0.0001) + rb->prune_tol;
 #pragma unroll
                     for (int k1 = 1; k1 <= NJ; ++k1)
                         if (bk[k1 - 1] < thr) s_list[(k1 - 1) * W * nobs + atomicAdd(&s_cnt[k1 - 1], 1)] = (unsigned short)((wi << 8) | j);
+                    s_dv[e * NE] = m0;
+#pragma unroll
+                    for (int ev = 1; ev < NE; ++ev) s_dv[e * NE + ev] = INFINITY;
                 }
                 __syncthreads();
                 {
@@ -466,30 +471,21 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                                 k1 = kk; ent = r_ / (2 * kk); v = r_ - ent * (2 * kk) + 1;
                             }
                         const int item = s_list[(k1 - 1) * W * nobs + ent], wi = item >> 8, j = item & 255;
-                        const int kv = kvoff(k1) + v;
-                        s_dt[(wi * NVT + kv) * nobs + j] = seg_seg_dist(s_en + (wi * NVT + kv) * 6, s_ob + j * 6);
+                        const double dis = seg_seg_dist(s_en + (wi * NVT + kvoff(k1) + v) * 6, s_ob + j * 6);
+                        // link k1 is at variant min(ev, 2 k1) at evaluation point ev: v < 2 k1 serves ev = v, v = 2 k1 every ev >= v
+                        double *dv = s_dv + (wi * nobs + j) * NE;
+                        const int evhi = (v == 2 * k1) ? NE - 1 : v;
+                        for (int ev = v; ev <= evhi; ++ev)
+                            __hip_atomic_fetch_min(dv + ev, dis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_min_f64
                     }
                 }
                 __syncthreads();
                 STAMP(11);                                  // 11: segment pairs
                 for (int e = tid; e < Wc * nobs; e += FT) {
                     const int j = e % nobs, wi = e / nobs;
-                    const double *tab = s_dt + (wi * NVT) * nobs + j;
-                    double dev[NE], m0 = INFINITY;
+                    double dev[NE];
 #pragma unroll
-                    for (int k1 = 1; k1 <= NJ; ++k1) m0 = fmin(m0, tab[kvoff(k1) * nobs]);
-                    const double thr = fmax(m0, 0.0001) + rb->prune_tol;
-#pragma unroll
-                    for (int ev = 0; ev < NE; ++ev) {
-                        double d = INFINITY;
-#pragma unroll
-                        for (int k1 = 1; k1 <= NJ; ++k1) {
-                            if (!(tab[kvoff(k1) * nobs] < thr)) continue;
-                            const double dis = tab[(kvoff(k1) + min(ev, 2 * k1)) * nobs];
-                            if (dis < d) d = dis;
-                        }
-                        dev[ev] = d;
-                    }
+                    for (int ev = 0; ev < NE; ++ev) dev[ev] = s_dv[e * NE + ev];
                     s_rhs[j * H + w0 + wi] = dev[0];
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) s_g[(j * H + w0 + wi) * NJ + m] = (dev[2 * m + 1] - dev[2 * m + 2]) / FD_EPS;
@@ -864,10 +860,10 @@ hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
 
 }  // namespace
 
-// linearisation scratch per waypoint of a tile: sin/cos, link end points, distance table, candidate lists (ushort)
+// linearisation scratch per waypoint of a tile: sin/cos, link end points, base distances, minima per evaluation point, candidate lists (ushort)
 static size_t lin_doubles_per_wp(int nj, int nobs)
 {
-    return (size_t)nj * 6 + (size_t)nvt(nj) * (6 + nobs) + ((size_t)nj * nobs + 3) / 4;
+    return (size_t)nj * 6 + (size_t)nvt(nj) * 6 + (size_t)nj * nobs + (size_t)nobs * (2 * nj + 1) + ((size_t)nj * nobs + 3) / 4;
 }
 
 // does the fused kernel's fixed LDS footprint (+ a minimal Y / linearisation region) fit a CU?
@@ -878,7 +874,7 @@ bool CFS_CAT(fused_fits, CFS_VARIANT)(int nj, int H, int nobs)
     const FusedLayout L = fused_layout(nj, H, nobs, QB, QB < CFS_PR ? QB : CFS_PR);
     const size_t avail = (160 * 1024 / CFS_WG_PER_CU) / 8 - 64;
     const size_t per_wp = lin_doubles_per_wp(nj, nobs);
-    return (size_t)L.total_fixed + std::max((size_t)4 * nn, per_wp) <= avail;
+    return (size_t)L.total_fixed + (size_t)4 * nn <= avail && (size_t)L.lin + per_wp <= avail;
 }
 
 // host: choose the capacities, fill qy / lin_w, launch
@@ -893,12 +889,12 @@ hipError_t CFS_CAT(launch_fused, CFS_VARIANT)(int nj, FusedParams p, hipStream_t
     int qy = (int)(region / nn);
     if (qy > nn) qy = nn;
     const size_t per_wp = lin_doubles_per_wp(nj, p.nobs);
-    int w = (int)(region / per_wp);
-    if (w > p.H) w = p.H;
+    int w = (int)((avail - L.lin) / per_wp);   // the linearisation may use the QP's work vectors too (layout)
     if (w < 1) return hipErrorInvalidValue;
+    w = (p.H + (p.H + w - 1) / w - 1) / ((p.H + w - 1) / w);   // equal tiles: ceil(H / number of tiles)
     p.qy = qy;
     p.lin_w = w;
-    const size_t need = (size_t)L.total_fixed + std::max((size_t)qy * nn, (size_t)w * per_wp);
+    const size_t need = std::max((size_t)L.total_fixed + (size_t)qy * nn, (size_t)L.lin + (size_t)w * per_wp);
     const size_t lds = need * 8;
     switch (nj * 1000 + QB) {
     case 2096: return launch_fused_inst<2, 96>(p, lds, s);
