@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0                                                       # MI
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", default="PSGCFS", choices=["CFS", "PSGCFS"],
                     help="headline solver: PSGCFS_FANUC is the solver BASELINE.json's batch-1024 config names; the other "
                          "one is measured too (shorter) and reported under 'other_mode'")
