@@ -200,6 +200,41 @@ int cfs_get_con(cfs_problem *p, int B, const double *x_, const double *u, const 
 int cfs_qp(cfs_problem *p, int B, const double *lin, const double *u_lin, const double *xR1,
            const double *dist, const double *grad, double *u, double *lambda, int *qp_iter, int *status);
 
+/* ---- mesh obstacles -----------------------------------------------------
+ * The reference measures the arm against a surface with `[dis, points] = point2surface_dis(pos{i}.p, obs)`
+ * (M200i/dist_arm_surf_200i.m:21, Lib/functions/dist_arm_surface.m:43) and loads its maps with stlread
+ * (Lib/functions/MapFromSTL.m:1-11), but contains neither function.  The contract here is the build's own:
+ * dis = min over the triangles of the Euclidean distance between the link axis and the triangle (0 when they
+ * intersect); points = [closest point on the link axis ; closest point on the mesh]; equal distances resolve
+ * to the smaller parameter along the axis.  A cfs_mesh owns the device copy of the triangles and of a bounding
+ * volume hierarchy; it lives on the device selected with cfs_set_device at creation. */
+typedef struct cfs_mesh cfs_mesh; /* opaque */
+
+/* vertices: nv x 3 (x, y, z per row); triangles: nt x 3 vertex indices (0-based); HOST pointers */
+int cfs_mesh_create(const double *vertices, int nv, const int *triangles, int nt, cfs_mesh **out);
+/* binary STL file.  map_from_stl != 0 applies Lib/functions/MapFromSTL.m:6-10 (every axis shifted to start at 0,
+ * y -= 100, then (x, y, z) <- (z, x, y)); every coordinate is finally multiplied by `scale` (the maps are in mm). */
+int cfs_mesh_load_stl(const char *path, double scale, int map_from_stl, cfs_mesh **out);
+/* any output may be NULL; bbox6 = [min xyz, max xyz] */
+int cfs_mesh_info(const cfs_mesh *m, int *ntri, int *nnodes, int *depth, double *bbox6);
+void cfs_mesh_destroy(cfs_mesh *m);
+
+/* point2surface_dis for n segments (HOST pointers): segs n x 6 = [p(:,1); p(:,2)]; dis n;
+ * points n x 6 (may be NULL); tri n = index of the closest triangle in the caller's list (may be NULL) */
+int cfs_mesh_segment_distance(const cfs_mesh *m, int n, const double *segs, double *dis, double *points, int *tri);
+
+/* dist_arm_surf_200i (M200i/dist_arm_surf_200i.m:1-29) for N poses (HOST pointers): theta N x njoint;
+ * d N; linkid N (1-based, may be NULL); points N x 6 of the closest link (may be NULL).  Same near-zero
+ * surrogate (:22-24) and first-minimum rule (:25-28) as cfs_dist_arm. */
+int cfs_dist_arm_mesh(const cfs_robot *robot, int njoint, int N, const double *theta, const cfs_mesh *m,
+                      double *d, int *linkid, double *points);
+
+/* From now on the LAST nmesh of the handle's nobs obstacles are these meshes (their entries of cfs_batch_in.obs are
+ * ignored; margin[] still applies per obstacle): every later solve measures the arm against them with the contract
+ * above, rows ordered as get_con orders obstacles (Lib/CFS_FANUC.m:111).  nmesh = 0 restores line obstacles only.
+ * The meshes must outlive the solves. */
+int cfs_problem_set_meshes(cfs_problem *p, int nmesh, const cfs_mesh *const *meshes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,13 @@ SYMBOLS = [
     ("cfs_linearize", C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     ("cfs_get_con", C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
     ("cfs_qp", C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("cfs_mesh_create", C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    ("cfs_mesh_load_stl", C.c_int, [C.c_char_p, C.c_double, C.c_int, C.POINTER(_P)]),
+    ("cfs_mesh_info", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    ("cfs_mesh_destroy", None, [_P]),
+    ("cfs_mesh_segment_distance", C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    ("cfs_dist_arm_mesh", C.c_int, [C.POINTER(cfs_robot), C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    ("cfs_problem_set_meshes", C.c_int, [_P, C.c_int, _P]),
 ]
 
 _lib = None

@@ -2,6 +2,7 @@
 // Owns the problem-family handle (device constants + workspace) and enqueues the kernels of one
 // solve on a caller-supplied stream without any host round trip inside the outer loop.
 #include "cfs_device.h"
+#include "cfs_host.h"
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -154,6 +155,11 @@ struct cfs_problem {
     DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg, Pt, u_hist, qu_hist;
     DevBuf<int> qp_status, qp_iter, noise_row, linkid;
     DevBuf<unsigned char> done;
+    // mesh obstacles (cfs_problem_set_meshes): the last nmesh of the nobs obstacles
+    int nmesh = 0;
+    DevBuf<DevMesh> meshes_d;
+    DevBuf<double> st_cost;
+    DevBuf<int> st_done;
     bool prof = false;
     std::vector<hipEvent_t> ev;   // 4 per profiled solve: gemm start/stop, fused start/stop
     void release_all()
@@ -167,7 +173,7 @@ struct cfs_problem {
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
         grad.release(); cost_new.release(); cost_old.release(); delta.release(); e_u.release();
         Yg.release(); Tg.release(); qp_status.release(); qp_iter.release(); noise_row.release();
-        linkid.release(); done.release();
+        linkid.release(); done.release(); meshes_d.release(); st_cost.release(); st_done.release();
     }
 };
 
@@ -176,6 +182,17 @@ static unsigned long long *g_stamps = nullptr;
 static int g_stamps_B = 0;
 static double *g_dbg = nullptr;
 static int g_dbg_b = -1, g_dbg_cap = 0;
+
+int cfs_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+int cfs_current_device() { return g_device; }
+void cfs_build_dev_robot(const cfs_robot &r, DevRobot &d) { build_dev_robot(r, d); }
 
 // Tier of the fused kernel (cfs_device.h).  Two problems per CU win whenever they fit: measured on config 3, PSGCFS
 // 3.6 -> 2.3 ms per solve with w2s, CFS 5.8 -> 5.6 ms with w2m (its infeasibility proofs run active sets of ~100 rows).
@@ -242,6 +259,10 @@ static int check_robot(const cfs_robot *r, int nj)
     if (r->kind == CFS_ROBOT_2L && nj > 2) return fail(CFS_ERR_INVALID_ARG, "the 2L model has 2 joints");
     return CFS_SUCCESS;
 }
+
+}  // extern "C"
+int cfs_check_robot(const cfs_robot *r, int nj) { return check_robot(r, nj); }
+extern "C" {
 
 int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
 {
@@ -482,7 +503,25 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     fp.u_hist = (p->d.mode == CFS_MODE_CFS && K > 0) ? p->u_hist.p : nullptr;
     { const char *e = getenv("CFS_OPT"); fp.opt = e ? atoi(e) : 0; }
     (void)nx;
-    HIPCHK(launch_fused(nj, fp, s));
+    if (p->nmesh == 0) {
+        HIPCHK(launch_fused(nj, fp, s));
+    } else {
+        // Mesh obstacles are linearised by their own kernel (hierarchy traversals do not fit the fused kernel's register
+        // budget), which needs the current iterate: one outer iteration per launch, state carried through HBM.  Every
+        // launch is enqueued up front; finished problems return at once, so there is still no host round trip.
+        LinMeshParams lm;
+        lm.rb = p->rb.p; lm.B = B; lm.H = p->d.H; lm.nmesh = p->nmesh; lm.meshes = p->meshes_d.p;
+        lm.dist = p->dist.p; lm.grad = p->grad.p;
+        fp.nmesh = p->nmesh; fp.ext_dist = p->dist.p; fp.ext_grad = p->grad.p; fp.max_launch_iters = 1;
+        fp.st_qu = p->qu.p; fp.st_cost = p->st_cost.p; fp.st_noise = p->noise_row.p; fp.st_done = p->st_done.p;
+        for (int it = 0; it < std::max(K, 1); ++it) {
+            lm.x_ = it == 0 ? in->x_init : out->x_;
+            lm.status_done = it == 0 ? nullptr : p->st_done.p;
+            HIPCHK(launch_linearize_mesh(nj, lm, s));
+            fp.resume = it > 0;
+            HIPCHK(launch_fused(nj, fp, s));
+        }
+    }
     if (p->prof) {
         HIPCHK(hipEventRecord(e4[3], s));
         for (int k = 0; k < 4; ++k) p->ev.push_back(e4[k]);
@@ -601,6 +640,30 @@ int cfs_build_terms_device(cfs_problem *p, int B, const double *x0, const double
     t.x0 = x0; t.xg = xg; t.x_init = x_init; t.xR1 = xR1; t.ff = ff; t.caug = caug;
     launch_build_terms(t, reinterpret_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
+    return CFS_SUCCESS;
+}
+
+int cfs_problem_set_meshes(cfs_problem *p, int nmesh, const cfs_mesh *const *meshes)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    if (nmesh < 0 || nmesh > p->d.nobs) return fail(CFS_ERR_INVALID_ARG, "nmesh %d outside 0..nobs=%d", nmesh, p->d.nobs);
+    if (nmesh > 0 && !meshes) return fail(CFS_ERR_INVALID_ARG, "meshes is NULL");
+    HIPCHK(hipSetDevice(p->device));
+    std::vector<DevMesh> v(nmesh);
+    for (int i = 0; i < nmesh; ++i) {
+        if (!meshes[i]) return fail(CFS_ERR_INVALID_ARG, "meshes[%d] is NULL", i);
+        if (meshes[i]->device != p->device) return fail(CFS_ERR_INVALID_ARG, "meshes[%d] lives on device %d, the problem on %d", i, meshes[i]->device, p->device);
+        v[i] = meshes[i]->view();
+    }
+    p->meshes_d.release(); p->st_cost.release(); p->st_done.release();
+    p->nmesh = 0;
+    if (nmesh > 0) {
+        HIPCHK(p->meshes_d.alloc(nmesh));
+        HIPCHK(p->st_cost.alloc(2 * (size_t)p->d.max_batch));
+        HIPCHK(p->st_done.alloc(p->d.max_batch));
+        HIPCHK(hipMemcpy(p->meshes_d.p, v.data(), sizeof(DevMesh) * nmesh, hipMemcpyHostToDevice));
+        p->nmesh = nmesh;
+    }
     return CFS_SUCCESS;
 }
 

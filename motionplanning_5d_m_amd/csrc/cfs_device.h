@@ -149,6 +149,16 @@ struct FusedParams {
     unsigned long long *stamps;  // optional: 16 cycle accumulators per problem (developer aid)
     int opt;                     // developer A/B switches (bit 0: gather w only and roll it on the fly)
     double *u_hist;              // CFS: B x max_o_iter x nn log of u per outer iteration (cost history computed afterwards)
+    // mesh obstacles: the last nmesh of the nobs obstacles; their rows come from cfs_linearize_mesh_kernel, which needs the
+    // current iterate, so the host drives such solves one outer iteration per launch and the state travels through HBM
+    int nmesh;
+    const double *ext_dist;      // B x nmesh x H
+    const double *ext_grad;      // B x nmesh x H x NJ
+    int resume;                  // 0: constructor state (CFS_FANUC.m:55-58), 1: continue from u / x_ / iter_O / total_iter / status and st_*
+    int max_launch_iters;        // outer iterations per launch (0: run to the end)
+    double *st_qu;               // B x nn      QQ*u
+    double *st_cost;             // B x 2       cost_new, cost_old
+    int *st_noise, *st_done;     // B           noise rows consumed; 1 when the problem has finished
 };
 // cfs_fused.hip is compiled into three tiers (workgroups per CU / register-resident columns of the inverse Gram matrix):
 //   w1  1 / 64  whole CU per problem: longest on-chip active sets

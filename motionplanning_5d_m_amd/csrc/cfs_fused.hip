@@ -359,7 +359,16 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     double cost_new = P.caug[b], cost_old = 100000.0;      // get_cost(zeros) = caug; EVAL.m:29
     int iter_O = 1, total_iter = 0, noise_row = 0, status = CFS_OK_MAXITER;
     bool done = false;
-    {
+    const int nseg = nobs - P.nmesh;                       // obstacles [nseg, nobs) are meshes, linearised by cfs_mesh.hip
+    int launched = 0;
+    if (P.resume) {                                        // continue a solve that is driven one outer iteration per launch
+        for (int e = tid; e < NX; e += FT) s_x[e] = P.x_[(size_t)b * NX + e];
+        for (int e = tid; e < HN; e += FT) { s_u[e] = P.u[(size_t)b * nn + e]; s_qu[e] = P.st_qu[(size_t)b * nn + e]; }
+        cost_new = P.st_cost[2 * b]; cost_old = P.st_cost[2 * b + 1];
+        iter_O = P.iter_O[b]; total_iter = P.total_iter[b]; status = P.status[b];
+        noise_row = P.st_noise[b]; done = P.st_done[b] != 0;
+        __syncthreads();
+    } else {
         double d2 = 0.0;
         for (int e = tid; e < NX; e += FT) { const double v = s_x[e] - 1.0; d2 += v * v; }   // x_old = ones (EVAL.m:47)
         d2 = block_sum(d2, red, tid);
@@ -378,8 +387,8 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             double *s_sc = lds + L.lin;                      // [W][NJ][3][2] sin, cos of theta, theta+eps/2, theta-eps/2 (minus the joint offset)
             double *s_en = s_sc + W * NJ * 6;                // [W][NVT][6]  capsule end points of every link variant
             double *s_bd = s_en + W * NVT * 6;               // [W][NJ][nobs] base-pose distance of every link
-            double *s_dv = s_bd + W * NJ * nobs;             // [W][nobs][NE] min over the links at every evaluation point of num_jac
-            unsigned short *s_list = reinterpret_cast<unsigned short *>(s_dv + W * nobs * NE);    // [NJ][W*nobs] (wi << 8 | obstacle)
+            double *s_dv = s_bd + W * NJ * nseg;             // [W][nobs][NE] min over the links at every evaluation point of num_jac
+            unsigned short *s_list = reinterpret_cast<unsigned short *>(s_dv + W * nseg * NE);    // [NJ][W*nobs] (wi << 8 | obstacle)
             int *s_cnt = s_free;                             // candidates per link (the QP's free-slot stack is idle here)
             for (int w0 = 0; w0 < H; w0 += W) {
                 const int Wc = min(W, H - w0);
@@ -434,24 +443,24 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 STAMP(10);                                  // 10: sincos + link transforms
                 // Base-pose distance of every link (dist_arm_3D_200i_2.m:16-26), link index slow so the point /
                 // segment branch of distLinSeg is wave-uniform.
-                for (int e = tid; e < NJ * Wc * nobs; e += FT) {
-                    const int j = e % nobs, wi = (e / nobs) % Wc, k0 = e / (nobs * Wc);
-                    s_bd[(wi * NJ + k0) * nobs + j] = seg_seg_dist(s_en + (wi * NVT + kvoff(k0 + 1)) * 6, s_ob + j * 6);
+                for (int e = tid; e < NJ * Wc * nseg; e += FT) {
+                    const int j = e % nseg, wi = (e / nseg) % Wc, k0 = e / (nseg * Wc);
+                    s_bd[(wi * NJ + k0) * nseg + j] = seg_seg_dist(s_en + (wi * NVT + kvoff(k0 + 1)) * 6, s_ob + j * 6);
                 }
                 if (tid < NJ) s_cnt[tid] = 0;
                 __syncthreads();
                 // num_jac only needs min over the links at 2nj shifted poses.  A link whose base distance exceeds
                 // max(min, 1e-4) by prune_tol can neither become the minimum nor reach the near-zero surrogate at any
                 // of them (see DevRobot::prune_tol), so only the other links are evaluated there: same minima, bit for bit.
-                for (int e = tid; e < Wc * nobs; e += FT) {
-                    const int j = e % nobs, wi = e / nobs;
+                for (int e = tid; e < Wc * nseg; e += FT) {
+                    const int j = e % nseg, wi = e / nseg;
                     double bk[NJ], m0 = INFINITY;
 #pragma unroll
-                    for (int k1 = 1; k1 <= NJ; ++k1) { bk[k1 - 1] = s_bd[(wi * NJ + k1 - 1) * nobs + j]; if (bk[k1 - 1] < m0) m0 = bk[k1 - 1]; }
+                    for (int k1 = 1; k1 <= NJ; ++k1) { bk[k1 - 1] = s_bd[(wi * NJ + k1 - 1) * nseg + j]; if (bk[k1 - 1] < m0) m0 = bk[k1 - 1]; }
                     const double thr = fmax(m0, 0.0001) + rb->prune_tol;
 #pragma unroll
                     for (int k1 = 1; k1 <= NJ; ++k1)
-                        if (bk[k1 - 1] < thr) s_list[(k1 - 1) * W * nobs + atomicAdd(&s_cnt[k1 - 1], 1)] = (unsigned short)((wi << 8) | j);
+                        if (bk[k1 - 1] < thr) s_list[(k1 - 1) * W * nseg + atomicAdd(&s_cnt[k1 - 1], 1)] = (unsigned short)((wi << 8) | j);
                     s_dv[e * NE] = m0;
 #pragma unroll
                     for (int ev = 1; ev < NE; ++ev) s_dv[e * NE + ev] = INFINITY;
@@ -470,10 +479,10 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                                 const int r_ = e - offs[kk - 1];
                                 k1 = kk; ent = r_ / (2 * kk); v = r_ - ent * (2 * kk) + 1;
                             }
-                        const int item = s_list[(k1 - 1) * W * nobs + ent], wi = item >> 8, j = item & 255;
+                        const int item = s_list[(k1 - 1) * W * nseg + ent], wi = item >> 8, j = item & 255;
                         const double dis = seg_seg_dist(s_en + (wi * NVT + kvoff(k1) + v) * 6, s_ob + j * 6);
                         // link k1 is at variant min(ev, 2 k1) at evaluation point ev: v < 2 k1 serves ev = v, v = 2 k1 every ev >= v
-                        double *dv = s_dv + (wi * nobs + j) * NE;
+                        double *dv = s_dv + (wi * nseg + j) * NE;
                         const int evhi = (v == 2 * k1) ? NE - 1 : v;
                         for (int ev = v; ev <= evhi; ++ev)
                             __hip_atomic_fetch_min(dv + ev, dis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_min_f64
@@ -481,8 +490,8 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 }
                 __syncthreads();
                 STAMP(11);                                  // 11: segment pairs
-                for (int e = tid; e < Wc * nobs; e += FT) {
-                    const int j = e % nobs, wi = e / nobs;
+                for (int e = tid; e < Wc * nseg; e += FT) {
+                    const int j = e % nseg, wi = e / nseg;
                     double dev[NE];
 #pragma unroll
                     for (int ev = 0; ev < NE; ++ev) dev[ev] = s_dv[e * NE + ev];
@@ -492,6 +501,12 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 }
                 __syncthreads();
             }
+        }
+
+        if (P.nmesh > 0) {   // rows of the mesh obstacles: linearised at this iterate by cfs_linearize_mesh_kernel (cfs_mesh.hip)
+            for (int e = tid; e < P.nmesh * H; e += FT) s_rhs[nseg * H + e] = P.ext_dist[(size_t)b * P.nmesh * H + e];
+            for (int e = tid; e < P.nmesh * HN; e += FT) s_g[nseg * HN + e] = P.ext_grad[(size_t)b * P.nmesh * HN + e];
+            __syncthreads();
         }
 
         // =========================================================================================
@@ -768,6 +783,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         total_iter += iters;
         if (qp_status != QP_OK) {        // the reference would crash here (CFS_FANUC.m:92); report instead
             status = qp_status == QP_INFEASIBLE ? CFS_QP_INFEASIBLE : CFS_NUMERIC;
+            done = true;
             break;
         }
 
@@ -834,6 +850,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         ++iter_O;                                              // CFS_FANUC.m:77
         if (sqrt(dx2) < P.epsilon_O) { done = true; status = CFS_OK_CONVERGED; }     // EVAL.m:64-68
         else if (iter_O > P.max_o_iter) { done = true; status = CFS_OK_MAXITER; }    // EVAL.m:69-72
+        if (P.max_launch_iters > 0 && ++launched >= P.max_launch_iters) break;        // the host relaunches (mesh obstacles)
     }
 
     // ---- results -----------------------------------------------------------------------------------
@@ -841,6 +858,10 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     for (int e = tid; e < HN; e += FT) P.u[(size_t)b * nn + e] = s_u[e];
     for (int e = tid; e < NX; e += FT) P.x_[(size_t)b * NX + e] = s_x[e];
     if (tid == 0) { P.iter_O[b] = iter_O; P.total_iter[b] = total_iter; P.status[b] = status; }
+    if (P.st_qu) {                                         // state for the next launch of a host-driven solve
+        for (int e = tid; e < HN; e += FT) P.st_qu[(size_t)b * nn + e] = s_qu[e];
+        if (tid == 0) { P.st_cost[2 * b] = cost_new; P.st_cost[2 * b + 1] = cost_old; P.st_noise[b] = noise_row; P.st_done[b] = done ? 1 : 0; }
+    }
     if (P.stamps && tid == 0) for (int k = 0; k < 12; ++k) P.stamps[(size_t)b * 12 + k] = s_acc[k];
 }
 

@@ -1,0 +1,47 @@
+// cfs_host.h -- host-side helpers shared by the translation units of libcfs_hip.so (not part of the C ABI).
+#pragma once
+#include "cfs_device.h"
+#include <vector>
+
+int cfs_fail(int code, const char *fmt, ...);            // records the message of cfs_last_error(), returns code
+int cfs_current_device();                                // device chosen with cfs_set_device
+int cfs_check_robot(const cfs_robot *r, int nj);         // CFS_SUCCESS or an error code (message recorded)
+void cfs_build_dev_robot(const cfs_robot &r, DevRobot &d);
+
+#define CFS_HIPCHK(call)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return cfs_fail(CFS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+// ---- mesh obstacles (cfs_mesh.hip) --------------------------------------------------------------
+struct BvhNode {                 // 64 B; leaf when count > 0
+    double lo[3], hi[3];
+    int left, right;             // children (inner nodes)
+    int first, count;            // triangles [first, first + count) of the leaf, in BVH order
+};
+struct DevMesh {                 // device view of one mesh
+    const BvhNode *nodes;
+    const double *tri;           // nt x 9 (A, B, C), in BVH order
+    const int *orig;             // BVH order -> index in the caller's triangle list
+    int nnodes, nt;
+};
+struct cfs_mesh {
+    int device = 0, nt = 0, nnodes = 0, depth = 0;
+    double bbox[6] = {0, 0, 0, 0, 0, 0};
+    BvhNode *nodes_d = nullptr;
+    double *tri_d = nullptr;
+    int *orig_d = nullptr;
+    DevMesh view() const { return DevMesh{nodes_d, tri_d, orig_d, nnodes, nt}; }
+};
+
+struct LinMeshParams {           // distance + literal finite-difference Jacobian against mesh obstacles
+    const DevRobot *rb;
+    int B, H, nmesh;
+    const DevMesh *meshes;       // device array [nmesh]
+    const double *x_;            // B x (H*2*NJ)
+    const int *status_done;      // B, may be null: problems whose entry is non-zero have finished and are skipped
+    double *dist;                // B x nmesh x H
+    double *grad;                // B x nmesh x H x NJ
+};
+hipError_t launch_linearize_mesh(int nj, const LinMeshParams &p, hipStream_t s);

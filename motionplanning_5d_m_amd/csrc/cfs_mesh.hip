@@ -1,0 +1,647 @@
+// cfs_mesh.hip -- mesh obstacles: binary-STL loader, BVH, segment-to-mesh distance
+// (the `point2surface_dis` the reference calls but does not contain: M200i/dist_arm_surf_200i.m:21,
+// Lib/functions/dist_arm_surface.m:43), dist_arm over a mesh, and the linearisation (distance + literal
+// num_jac gradient) of mesh obstacles that feeds the fused solver.
+//
+// Contract (the build's own, DESIGN.md "Mesh obstacles"): dis = min over triangles of the Euclidean distance
+// between the link axis and the triangle (0 when they intersect); points = [closest point on the axis; closest
+// point on the mesh]; equal distances resolve to the smaller parameter along the axis, so the answer does not
+// depend on the traversal order.  The hierarchy only prunes: a node is skipped when a rigorous lower bound of
+// its distance exceeds the incumbent.
+#include "cfs_geom_dev.h"
+#include "cfs_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+namespace {
+
+constexpr int MESH_THREADS = 128;
+constexpr int MESH_STACK = 40;              // >= depth of the balanced hierarchy + 2 (checked at build time)
+constexpr int LEAF_TRIS = 4;
+
+// ---- device geometry -------------------------------------------------------------------------------
+__device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void sub3(const double *a, const double *b, double *c) { c[0] = a[0] - b[0]; c[1] = a[1] - b[1]; c[2] = a[2] - b[2]; }
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+
+// Lib/functions/distLinSeg.m:23-91 with both outputs: distance, parameter t on the first segment, closest points
+__device__ double seg_seg_full(const double *p1s, const double *p1e, const double *p2s, const double *p2e, double *t_out, double *pts)
+{
+    double d1[3], d2[3], d12[3];
+    sub3(p1e, p1s, d1); sub3(p2e, p2s, d2); sub3(p2s, p1s, d12);
+    const double D1 = dot3(d1, d1), D2 = dot3(d2, d2), S1 = dot3(d1, d12), S2 = dot3(d2, d12), R = dot3(d1, d2);
+    const double den = D1 * D2 - R * R;
+    double t, u;
+    if (D1 == 0.0 || D2 == 0.0) {
+        if (D1 != 0.0) { u = 0.0; t = clamp01(S1 / D1); }
+        else if (D2 != 0.0) { t = 0.0; u = clamp01(-S2 / D2); }
+        else { t = 0.0; u = 0.0; }
+    } else if (den == 0.0) {
+        t = 0.0;
+        u = -S2 / D2;
+        const double uf = clamp01(u);
+        if (uf != u) { t = clamp01((uf * R + S1) / D1); u = uf; }
+    } else {
+        t = clamp01((S1 * D2 - S2 * R) / den);
+        u = (t * R - S2) / D2;
+        const double uf = clamp01(u);
+        if (uf != u) { t = clamp01((uf * R + S1) / D1); u = uf; }
+    }
+    double e[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        e[r] = d1[r] * t - d2[r] * u - d12[r];
+        pts[r] = p1s[r] + d1[r] * t;
+        pts[3 + r] = p2s[r] + d2[r] * u;
+    }
+    *t_out = t;
+    return sqrt(dot3(e, e));
+}
+
+// closest point of triangle ABC to P (Voronoi regions; Ericson, Real-Time Collision Detection 5.1.5)
+__device__ void closest_pt_triangle(const double *P, const double *A, const double *B, const double *C, double *Q)
+{
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+    sub3(B, A, ab); sub3(C, A, ac); sub3(P, A, ap);
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    if (d1 <= 0.0 && d2 <= 0.0) { Q[0] = A[0]; Q[1] = A[1]; Q[2] = A[2]; return; }
+    sub3(P, B, bp);
+    const double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+    if (d3 >= 0.0 && d4 <= d3) { Q[0] = B[0]; Q[1] = B[1]; Q[2] = B[2]; return; }
+    const double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+        const double v = d1 / (d1 - d3);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Q[r] = A[r] + v * ab[r];
+        return;
+    }
+    sub3(P, C, cp);
+    const double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    if (d6 >= 0.0 && d5 <= d6) { Q[0] = C[0]; Q[1] = C[1]; Q[2] = C[2]; return; }
+    const double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+        const double w = d2 / (d2 - d6);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Q[r] = A[r] + w * ac[r];
+        return;
+    }
+    const double va = d3 * d6 - d5 * d4;
+    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+        const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Q[r] = B[r] + w * (C[r] - B[r]);
+        return;
+    }
+    const double denom = 1.0 / (va + vb + vc);
+    const double v = vb * denom, w = vc * denom;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Q[r] = A[r] + ab[r] * v + ac[r] * w;
+}
+
+struct Best {                  // incumbent of one query
+    double d, t;
+    double pts[6];
+    int tri;
+};
+__device__ __forceinline__ void take(Best &b, double dis, double t, const double *pl, const double *pm, int tri)
+{
+    if (dis < b.d || (dis == b.d && t < b.t)) {
+        b.d = dis; b.t = t; b.tri = tri;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { b.pts[r] = pl[r]; b.pts[3 + r] = pm[r]; }
+    }
+}
+
+// segment P0P1 against triangle T (9 doubles)
+__device__ void seg_tri_update(const double *P0, const double *P1, const double *T, int tri, Best &b)
+{
+    const double *A = T, *B = T + 3, *C = T + 6;
+    double d[3], ab[3], ac[3], n[3], e0[3], e1[3];
+    sub3(P1, P0, d);
+    const double D = dot3(d, d);
+    sub3(B, A, ab); sub3(C, A, ac);
+    cross3(ab, ac, n);
+    if (dot3(n, n) > 0.0) {                                  // proper triangle: does the segment pierce it?
+        sub3(P0, A, e0); sub3(P1, A, e1);
+        const double s0 = dot3(n, e0), s1 = dot3(n, e1);
+        if (s0 * s1 <= 0.0 && s0 != s1) {
+            const double t = s0 / (s0 - s1);
+            double X[3], xa[3], xb[3], xc[3], bc[3], ca[3], c0[3], c1[3], c2[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) X[r] = P0[r] + t * d[r];
+            sub3(X, A, xa); sub3(X, B, xb); sub3(X, C, xc);
+            sub3(C, B, bc); sub3(A, C, ca);
+            cross3(ab, xa, c0); cross3(bc, xb, c1); cross3(ca, xc, c2);
+            if (dot3(n, c0) >= 0.0 && dot3(n, c1) >= 0.0 && dot3(n, c2) >= 0.0) { take(b, 0.0, t, X, X, tri); return; }
+        }
+    }
+    {
+        double Q[3], e[3];
+        closest_pt_triangle(P0, A, B, C, Q);
+        sub3(P0, Q, e);
+        take(b, sqrt(dot3(e, e)), 0.0, P0, Q, tri);
+        closest_pt_triangle(P1, A, B, C, Q);
+        sub3(P1, Q, e);
+        take(b, sqrt(dot3(e, e)), D == 0.0 ? 0.0 : 1.0, P1, Q, tri);
+    }
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+        const double *ea = T + 3 * k, *eb = T + 3 * ((k + 1) % 3);
+        double p6[6], tt;
+        const double dis = seg_seg_full(P0, P1, ea, eb, &tt, p6);
+        double tpar = 0.0;
+        if (D != 0.0) { double e[3]; sub3(p6, P0, e); tpar = dot3(e, d) / D; }
+        take(b, dis, tpar, p6, p6 + 3, tri);
+    }
+}
+
+// rigorous lower bound of dist(segment, box): the segment is covered by 4 balls of radius |d|/8, and its own
+// bounding box is at least box-box distance away; any lower bound of a cover is a lower bound of the segment
+__device__ double node_lower_bound(const double *P0, const double *P1, const BvhNode &nd)
+{
+    double bb = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double lo = fmin(P0[r], P1[r]), hi = fmax(P0[r], P1[r]);
+        const double g = fmax(0.0, fmax(nd.lo[r] - hi, lo - nd.hi[r]));
+        bb += g * g;
+    }
+    bb = sqrt(bb);
+    double d[3];
+    sub3(P1, P0, d);
+    const double rad = sqrt(dot3(d, d)) * 0.125;
+    double sp = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double f = (2 * i + 1) * 0.125;
+        double g2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double c = P0[r] + f * d[r];
+            const double g = fmax(0.0, fmax(nd.lo[r] - c, c - nd.hi[r]));
+            g2 += g * g;
+        }
+        sp = fmin(sp, sqrt(g2));
+    }
+    // the balls' bound loses a few ulp in rad and the square roots: shave it so that it stays a lower bound
+    const double spb = (sp - rad) - 1e-12 * (sp + rad);
+    return fmax(bb * (1.0 - 1e-14), fmax(0.0, spb));
+}
+
+// nearest-first traversal; `stack` holds MESH_STACK ints private to the thread (LDS, strided)
+template <int STRIDE>
+__device__ void mesh_query(const DevMesh &m, const double *P0, const double *P1, int seed_tri, int *stack, Best &b)
+{
+    b.d = INFINITY; b.t = INFINITY; b.tri = -1;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) b.pts[r] = 0.0;
+    if (m.nt == 0) return;
+    if (seed_tri >= 0) seg_tri_update(P0, P1, m.tri + 9 * (size_t)seed_tri, seed_tri, b);   // incumbent from a nearby query
+    int sp = 0;
+    int cur = 0;
+    if (node_lower_bound(P0, P1, m.nodes[0]) > b.d) return;
+    for (;;) {
+        const BvhNode nd = m.nodes[cur];
+        if (nd.count > 0) {
+            for (int k = nd.first; k < nd.first + nd.count; ++k)
+                if (k != seed_tri) seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, b);
+            cur = -1;
+        } else {
+            const double ll = node_lower_bound(P0, P1, m.nodes[nd.left]);
+            const double lr = node_lower_bound(P0, P1, m.nodes[nd.right]);
+            const int nearc = ll <= lr ? nd.left : nd.right, farc = ll <= lr ? nd.right : nd.left;
+            const double ln = fmin(ll, lr), lf = fmax(ll, lr);
+            cur = -1;
+            if (ln <= b.d) {
+                cur = nearc;
+                if (lf <= b.d && sp < MESH_STACK) stack[(sp++) * STRIDE] = farc;   // bound re-checked when popped
+            }
+        }
+        while (cur < 0) {
+            if (sp == 0) return;
+            const int c = stack[(--sp) * STRIDE];
+            if (node_lower_bound(P0, P1, m.nodes[c]) <= b.d) cur = c;
+        }
+    }
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------
+struct SegQueryParams { DevMesh m; int n; const double *segs; double *dis, *pts; int *tri; };
+
+__global__ __launch_bounds__(MESH_THREADS) void cfs_mesh_seg_kernel(SegQueryParams P)
+{
+    __shared__ int s_stack[MESH_STACK * MESH_THREADS];
+    const int i = blockIdx.x * MESH_THREADS + threadIdx.x;
+    if (i >= P.n) return;
+    double seg[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) seg[r] = P.segs[(size_t)i * 6 + r];
+    Best b;
+    mesh_query<MESH_THREADS>(P.m, seg, seg + 3, -1, s_stack + threadIdx.x, b);
+    P.dis[i] = b.d;
+    if (P.pts)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) P.pts[(size_t)i * 6 + r] = b.pts[r];
+    if (P.tri) P.tri[i] = b.tri >= 0 ? P.m.orig[b.tri] : -1;
+}
+
+// dist_arm over a mesh (M200i/dist_arm_surf_200i.m:1-29): one thread per (pose, link), min over links in LDS
+struct ArmMeshParams { const DevRobot *rb; DevMesh m; int N, nj; const double *theta; double *d; int *linkid; double *pts; };
+
+__global__ __launch_bounds__(MESH_THREADS) void cfs_dist_arm_mesh_kernel(ArmMeshParams P)
+{
+    __shared__ int s_stack[MESH_STACK * MESH_THREADS];
+    __shared__ double s_dis[MESH_THREADS];
+    __shared__ double s_pts[MESH_THREADS * 6];
+    const int nj = P.nj, per = MESH_THREADS / nj;           // poses per workgroup
+    const int lp = threadIdx.x / nj, k = threadIdx.x - lp * nj;
+    const int pose = blockIdx.x * per + lp;
+    const bool live = lp < per && pose < P.N;
+    double dis = INFINITY;
+    if (live) {
+        const DevRobot *rb = P.rb;
+        double M[12], Mn[12], e6[6];
+        for (int k1 = 0; k1 <= k; ++k1) {                    // CapPos.m:13-20 up to this thread's link
+            double sn, cs;
+            sincos(P.theta[(size_t)pose * nj + k1] - rb->th_off[k1], &sn, &cs);
+            fk_step(rb, k1, sn, cs, k1 == 0 ? nullptr : M, Mn);
+            for (int q = 0; q < 12; ++q) M[q] = Mn[q];
+        }
+        link_ends(rb, k, M, e6);
+        Best b;
+        mesh_query<MESH_THREADS>(P.m, e6, e6 + 3, -1, s_stack + threadIdx.x, b);
+        dis = b.d;
+        if (fabs(dis) < 0.0001) {                            // dist_arm_surf_200i.m:22-24
+            const double qx = b.pts[0] - e6[3], qy = b.pts[1] - e6[4], qz = b.pts[2] - e6[5];
+            dis = -sqrt(qx * qx + qy * qy + qz * qz);
+        }
+        for (int r = 0; r < 6; ++r) s_pts[threadIdx.x * 6 + r] = b.pts[r];
+    }
+    s_dis[threadIdx.x] = dis;
+    __syncthreads();
+    if (live && k == 0) {
+        double d = INFINITY;
+        int id = 0;
+        for (int i = 0; i < nj; ++i) { const double v = s_dis[lp * nj + i]; if (v < d) { d = v; id = i + 1; } }   // :25-28, first minimum wins
+        P.d[pose] = d;
+        if (P.linkid) P.linkid[pose] = id;
+        if (P.pts && id > 0)
+            for (int r = 0; r < 6; ++r) P.pts[(size_t)pose * 6 + r] = s_pts[(lp * nj + id - 1) * 6 + r];
+    }
+}
+
+// Linearisation against mesh obstacles: the same scheme as cfs_fused.hip (link variants, base distances, pruned
+// candidates, minima per evaluation point of num_jac), the distance being a hierarchy query; the shifted poses
+// start from the base pose's winning triangle, so their traversals prune almost everything.
+constexpr int LM_W = 4;                                      // waypoints per workgroup
+template <int NJ>
+__global__ __launch_bounds__(MESH_THREADS) void cfs_linearize_mesh_kernel(LinMeshParams P)
+{
+    constexpr int NS = 2 * NJ, NVT = nvt(NJ), NE = 2 * NJ + 1;
+    __shared__ int s_stack[MESH_STACK * MESH_THREADS];
+    __shared__ DevRobot s_rb;
+    __shared__ double s_sc[LM_W * NJ * 6];
+    __shared__ double s_tm[LM_W * NVT * 12];
+    __shared__ double s_en[LM_W * NVT * 6];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];   // [W][NJ][nmesh] base distance, [W][nmesh][NE] minima, ints: base triangle
+    const int nmesh = P.nmesh, tid = threadIdx.x;
+    const int tiles = (P.H + LM_W - 1) / LM_W;
+    const int b = blockIdx.x / tiles, w0 = (blockIdx.x % tiles) * LM_W;
+    if (P.status_done && P.status_done[b] != 0) return;
+    const int W = min(LM_W, P.H - w0);
+    double *s_bd = dyn;
+    double *s_dv = s_bd + LM_W * NJ * nmesh;
+    int *s_bt = reinterpret_cast<int *>(s_dv + LM_W * nmesh * NE);
+    {
+        const double *src = reinterpret_cast<const double *>(P.rb);
+        double *dst = reinterpret_cast<double *>(&s_rb);
+        for (int e = tid; e < (int)(sizeof(DevRobot) / 8); e += MESH_THREADS) dst[e] = src[e];
+    }
+    __syncthreads();
+    const DevRobot *rb = &s_rb;
+    for (int e = tid; e < W * NJ * 3; e += MESH_THREADS) {
+        const int var = e % 3, m = (e / 3) % NJ, wi = e / (3 * NJ);
+        double x = P.x_[(size_t)b * P.H * NS + (size_t)(w0 + wi) * NS + m];
+        if (var == 1) x = x + FD_EPS / 2;                 // num_jac.m:11
+        else if (var == 2) x = x - FD_EPS / 2;            // num_jac.m:13
+        x = x - rb->th_off[m];                            // dist_arm_surf_200i.m:10-12 (same offset as dist_arm_3D_200i_2.m:11)
+        double sn, cs;
+        sincos(x, &sn, &cs);
+        s_sc[((wi * NJ + m) * 3 + var) * 2 + 0] = sn;
+        s_sc[((wi * NJ + m) * 3 + var) * 2 + 1] = cs;
+    }
+    __syncthreads();
+    for (int k1 = 1; k1 <= NJ; ++k1) {                    // link k has 2k+1 distinct transforms (see cfs_fused.hip)
+        const int nv = 2 * k1 + 1;
+        for (int e = tid; e < W * nv; e += MESH_THREADS) {
+            const int v = e % nv, wi = e / nv;
+            const int avar = (v == 2 * k1 - 1) ? 1 : (v == 2 * k1 ? 2 : 0);
+            const int pv = min(v, 2 * (k1 - 1));
+            const double sn = s_sc[((wi * NJ + (k1 - 1)) * 3 + avar) * 2 + 0];
+            const double cs = s_sc[((wi * NJ + (k1 - 1)) * 3 + avar) * 2 + 1];
+            const double *par = (k1 == 1) ? nullptr : s_tm + (wi * NVT + kvoff(k1 - 1) + pv) * 12;
+            double M[12], e6[6];
+            fk_step(rb, k1 - 1, sn, cs, par, M);
+            link_ends(rb, k1 - 1, M, e6);
+            for (int q = 0; q < 12; ++q) s_tm[(wi * NVT + kvoff(k1) + v) * 12 + q] = M[q];
+            for (int q = 0; q < 6; ++q) s_en[(wi * NVT + kvoff(k1) + v) * 6 + q] = e6[q];
+        }
+        __syncthreads();
+    }
+    // base pose: every link against every mesh
+    for (int e = tid; e < W * NJ * nmesh; e += MESH_THREADS) {
+        const int jm = e % nmesh, k0 = (e / nmesh) % NJ, wi = e / (nmesh * NJ);
+        const double *a6 = s_en + (wi * NVT + kvoff(k0 + 1)) * 6;
+        Best bq;
+        mesh_query<MESH_THREADS>(P.meshes[jm], a6, a6 + 3, -1, s_stack + tid, bq);
+        double dis = bq.d;
+        if (fabs(dis) < 0.0001) {
+            const double qx = bq.pts[0] - a6[3], qy = bq.pts[1] - a6[4], qz = bq.pts[2] - a6[5];
+            dis = -sqrt(qx * qx + qy * qy + qz * qz);
+        }
+        s_bd[(wi * NJ + k0) * nmesh + jm] = dis;
+        s_bt[(wi * NJ + k0) * nmesh + jm] = bq.tri;
+    }
+    __syncthreads();
+    for (int e = tid; e < W * nmesh; e += MESH_THREADS) {
+        const int jm = e % nmesh, wi = e / nmesh;
+        double m0 = INFINITY;
+        for (int k0 = 0; k0 < NJ; ++k0) m0 = fmin(m0, s_bd[(wi * NJ + k0) * nmesh + jm]);
+        s_dv[e * NE] = m0;
+        for (int ev = 1; ev < NE; ++ev) s_dv[e * NE + ev] = INFINITY;
+    }
+    __syncthreads();
+    // shifted poses of the links that can be the minimum there (same pruning rule and margin as cfs_fused.hip)
+    for (int e = tid; e < W * nmesh * (NVT - NJ); e += MESH_THREADS) {
+        const int sv = e % (NVT - NJ), jm = (e / (NVT - NJ)) % nmesh, wi = e / ((NVT - NJ) * nmesh);
+        int k1 = 1, v = 1;                                 // sv enumerates (link k1, variant v = 1..2 k1)
+        {
+            int acc = 0;
+#pragma unroll
+            for (int kk = 1; kk <= NJ; ++kk) { if (sv >= acc && sv < acc + 2 * kk) { k1 = kk; v = sv - acc + 1; } acc += 2 * kk; }
+        }
+        const double bk = s_bd[(wi * NJ + k1 - 1) * nmesh + jm];
+        const double thr = fmax(s_dv[(wi * nmesh + jm) * NE], 0.0001) + rb->prune_tol;
+        if (!(bk < thr)) continue;
+        const double *a6 = s_en + (wi * NVT + kvoff(k1) + v) * 6;
+        Best bq;
+        mesh_query<MESH_THREADS>(P.meshes[jm], a6, a6 + 3, s_bt[(wi * NJ + k1 - 1) * nmesh + jm], s_stack + tid, bq);
+        double dis = bq.d;
+        if (fabs(dis) < 0.0001) {
+            const double qx = bq.pts[0] - a6[3], qy = bq.pts[1] - a6[4], qz = bq.pts[2] - a6[5];
+            dis = -sqrt(qx * qx + qy * qy + qz * qz);
+        }
+        double *dv = s_dv + (wi * nmesh + jm) * NE;
+        const int evhi = (v == 2 * k1) ? NE - 1 : v;
+        for (int ev = v; ev <= evhi; ++ev) __hip_atomic_fetch_min(dv + ev, dis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    for (int e = tid; e < W * nmesh; e += MESH_THREADS) {
+        const int jm = e % nmesh, wi = e / nmesh;
+        const double *dv = s_dv + e * NE;
+        const size_t o = ((size_t)b * nmesh + jm) * P.H + w0 + wi;
+        P.dist[o] = dv[0];
+        for (int m = 0; m < NJ; ++m) P.grad[o * NJ + m] = (dv[2 * m + 1] - dv[2 * m + 2]) / FD_EPS;   // num_jac.m:14
+    }
+}
+
+// ---- host: hierarchy ------------------------------------------------------------------------------------
+struct Builder {
+    const double *tri;             // nt x 9, caller order
+    std::vector<int> order;        // permutation being built
+    std::vector<double> cen;       // nt x 3 centroids
+    std::vector<BvhNode> nodes;
+    int depth = 0;
+
+    int build(int first, int count, int level)
+    {
+        depth = std::max(depth, level);
+        const int id = (int)nodes.size();
+        nodes.emplace_back();
+        BvhNode nd;
+        for (int r = 0; r < 3; ++r) { nd.lo[r] = INFINITY; nd.hi[r] = -INFINITY; }
+        double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = first; i < first + count; ++i) {
+            const double *T = tri + 9 * (size_t)order[i];
+            for (int v = 0; v < 3; ++v)
+                for (int r = 0; r < 3; ++r) { nd.lo[r] = std::min(nd.lo[r], T[3 * v + r]); nd.hi[r] = std::max(nd.hi[r], T[3 * v + r]); }
+            for (int r = 0; r < 3; ++r) { clo[r] = std::min(clo[r], cen[3 * (size_t)order[i] + r]); chi[r] = std::max(chi[r], cen[3 * (size_t)order[i] + r]); }
+        }
+        nd.left = nd.right = -1; nd.first = first; nd.count = 0;
+        if (count <= LEAF_TRIS) { nd.count = count; nodes[id] = nd; return id; }
+        int ax = 0;
+        for (int r = 1; r < 3; ++r) if (chi[r] - clo[r] > chi[ax] - clo[ax]) ax = r;
+        const int mid = first + count / 2;                    // median split: balanced, depth <= ceil(log2(nt)) + 1
+        std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                         [&](int a, int c) { const double ca = cen[3 * (size_t)a + ax], cc = cen[3 * (size_t)c + ax]; return ca < cc || (ca == cc && a < c); });
+        nd.left = build(first, mid - first, level + 1);
+        nd.right = build(mid, first + count - mid, level + 1);
+        nodes[id] = nd;
+        return id;
+    }
+};
+
+int upload_mesh(const std::vector<double> &tri9, cfs_mesh **out)
+{
+    const int nt = (int)(tri9.size() / 9);
+    for (double v : tri9) if (!std::isfinite(v)) return cfs_fail(CFS_ERR_INVALID_ARG, "mesh has a non-finite coordinate");
+    Builder bd;
+    bd.tri = tri9.data();
+    bd.order.resize(nt);
+    std::iota(bd.order.begin(), bd.order.end(), 0);
+    bd.cen.resize(3 * (size_t)nt);
+    for (int i = 0; i < nt; ++i)
+        for (int r = 0; r < 3; ++r) bd.cen[3 * (size_t)i + r] = (tri9[9 * (size_t)i + r] + tri9[9 * (size_t)i + 3 + r] + tri9[9 * (size_t)i + 6 + r]) / 3.0;
+    bd.nodes.reserve(2 * (size_t)nt / LEAF_TRIS + 8);
+    bd.build(0, nt, 1);
+    if (bd.depth + 2 > MESH_STACK) return cfs_fail(CFS_ERR_INVALID_ARG, "mesh hierarchy too deep (%d levels)", bd.depth);
+    std::vector<double> tri_o(9 * (size_t)nt);
+    for (int i = 0; i < nt; ++i) memcpy(&tri_o[9 * (size_t)i], &tri9[9 * (size_t)bd.order[i]], 72);
+    cfs_mesh *m = new (std::nothrow) cfs_mesh();
+    if (!m) return cfs_fail(CFS_ERR_ALLOC, "out of host memory");
+    m->device = cfs_current_device();
+    m->nt = nt; m->nnodes = (int)bd.nodes.size(); m->depth = bd.depth;
+    for (int r = 0; r < 3; ++r) { m->bbox[r] = bd.nodes[0].lo[r]; m->bbox[3 + r] = bd.nodes[0].hi[r]; }
+    hipError_t e = hipSetDevice(m->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->nodes_d), bd.nodes.size() * sizeof(BvhNode));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->tri_d), tri_o.size() * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->orig_d), (size_t)nt * 4);
+    if (e == hipSuccess) e = hipMemcpy(m->nodes_d, bd.nodes.data(), bd.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->tri_d, tri_o.data(), tri_o.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->orig_d, bd.order.data(), (size_t)nt * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        const int rc = cfs_fail(cfs_device_count() > 0 ? CFS_ERR_HIP : CFS_ERR_NO_DEVICE, "mesh upload failed: %s", hipGetErrorString(e));
+        cfs_mesh_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return CFS_SUCCESS;
+}
+
+}  // namespace
+
+hipError_t launch_linearize_mesh(int nj, const LinMeshParams &p, hipStream_t s)
+{
+    const int tiles = (p.H + LM_W - 1) / LM_W, NE = 2 * nj + 1;
+    const size_t dynb = ((size_t)LM_W * nj * p.nmesh + (size_t)LM_W * p.nmesh * NE) * 8 + (size_t)LM_W * nj * p.nmesh * 4 + 16;
+    const dim3 grid(p.B * tiles), block(MESH_THREADS);
+    switch (nj) {
+    case 2: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<2>, grid, block, dynb, s, p); break;
+    case 3: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<3>, grid, block, dynb, s, p); break;
+    case 4: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<4>, grid, block, dynb, s, p); break;
+    case 5: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<5>, grid, block, dynb, s, p); break;
+    case 6: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<6>, grid, block, dynb, s, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+extern "C" {
+
+int cfs_mesh_create(const double *vertices, int nv, const int *triangles, int nt, cfs_mesh **out)
+{
+    if (!out) return cfs_fail(CFS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!vertices || !triangles || nv < 3 || nt < 1) return cfs_fail(CFS_ERR_INVALID_ARG, "a mesh needs vertices and at least one triangle");
+    if (cfs_device_count() <= 0) return cfs_fail(CFS_ERR_NO_DEVICE, "no HIP device");
+    std::vector<double> tri9(9 * (size_t)nt);
+    for (int i = 0; i < nt; ++i)
+        for (int v = 0; v < 3; ++v) {
+            const int id = triangles[3 * (size_t)i + v];
+            if (id < 0 || id >= nv) return cfs_fail(CFS_ERR_INVALID_ARG, "triangle %d refers to vertex %d of %d", i, id, nv);
+            for (int r = 0; r < 3; ++r) tri9[9 * (size_t)i + 3 * v + r] = vertices[3 * (size_t)id + r];
+        }
+    return upload_mesh(tri9, out);
+}
+
+// binary STL (80-byte header, uint32 count, 50-byte records); map_from_stl applies Lib/functions/MapFromSTL.m:6-10
+// (shift every axis to start at 0, y -= 100, then (x, y, z) <- (z, x, y)) before the uniform `scale`
+int cfs_mesh_load_stl(const char *path, double scale, int map_from_stl, cfs_mesh **out)
+{
+    if (!out) return cfs_fail(CFS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!path) return cfs_fail(CFS_ERR_INVALID_ARG, "path is NULL");
+    if (!(scale > 0)) return cfs_fail(CFS_ERR_INVALID_ARG, "scale must be positive");
+    FILE *f = fopen(path, "rb");
+    if (!f) return cfs_fail(CFS_ERR_INVALID_ARG, "cannot open %s", path);
+    unsigned char head[84];
+    if (fread(head, 1, 84, f) != 84) { fclose(f); return cfs_fail(CFS_ERR_INVALID_ARG, "%s: shorter than an STL header", path); }
+    unsigned int nt;
+    memcpy(&nt, head + 80, 4);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    if (nt < 1 || sz != 84 + 50 * (long)nt) { fclose(f); return cfs_fail(CFS_ERR_INVALID_ARG, "%s: not a binary STL (%u triangles, %ld bytes)", path, nt, sz); }
+    fseek(f, 84, SEEK_SET);
+    std::vector<unsigned char> rec(50 * (size_t)nt);
+    const size_t got = fread(rec.data(), 50, nt, f);
+    fclose(f);
+    if (got != nt) return cfs_fail(CFS_ERR_INVALID_ARG, "%s: truncated", path);
+    std::vector<double> tri9(9 * (size_t)nt);
+    for (size_t i = 0; i < nt; ++i) {
+        float v[9];
+        memcpy(v, rec.data() + 50 * i + 12, 36);
+        for (int r = 0; r < 9; ++r) tri9[9 * i + r] = (double)v[r];
+    }
+    if (map_from_stl) {
+        double mn[3] = {INFINITY, INFINITY, INFINITY};
+        for (size_t i = 0; i < 3 * (size_t)nt; ++i)
+            for (int r = 0; r < 3; ++r) mn[r] = std::min(mn[r], tri9[3 * i + r]);
+        for (size_t i = 0; i < 3 * (size_t)nt; ++i) {
+            const double x = tri9[3 * i] - mn[0], y = (tri9[3 * i + 1] - mn[1]) - 100.0, z = tri9[3 * i + 2] - mn[2];
+            tri9[3 * i] = z; tri9[3 * i + 1] = x; tri9[3 * i + 2] = y;
+        }
+    }
+    for (double &v : tri9) v *= scale;
+    if (cfs_device_count() <= 0) return cfs_fail(CFS_ERR_NO_DEVICE, "no HIP device");
+    return upload_mesh(tri9, out);
+}
+
+int cfs_mesh_info(const cfs_mesh *m, int *ntri, int *nnodes, int *depth, double *bbox6)
+{
+    if (!m) return cfs_fail(CFS_ERR_INVALID_ARG, "mesh is NULL");
+    if (ntri) *ntri = m->nt;
+    if (nnodes) *nnodes = m->nnodes;
+    if (depth) *depth = m->depth;
+    if (bbox6) memcpy(bbox6, m->bbox, sizeof m->bbox);
+    return CFS_SUCCESS;
+}
+
+void cfs_mesh_destroy(cfs_mesh *m)
+{
+    if (!m) return;
+    if (m->nodes_d) (void)hipFree(m->nodes_d);
+    if (m->tri_d) (void)hipFree(m->tri_d);
+    if (m->orig_d) (void)hipFree(m->orig_d);
+    delete m;
+}
+
+// point2surface_dis for n segments (host arrays): dis[n], points[n x 6] (may be NULL), tri[n] (may be NULL)
+int cfs_mesh_segment_distance(const cfs_mesh *m, int n, const double *segs, double *dis, double *points, int *tri)
+{
+    if (!m || !segs || !dis || n < 1) return cfs_fail(CFS_ERR_INVALID_ARG, "mesh/segs/dis must be given, n >= 1");
+    CFS_HIPCHK(hipSetDevice(m->device));
+    double *d_seg = nullptr, *d_dis = nullptr, *d_pts = nullptr;
+    int *d_tri = nullptr;
+    int rc = CFS_SUCCESS;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_seg), (size_t)n * 48);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_dis), (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_pts), (size_t)n * 48);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_tri), (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_seg, segs, (size_t)n * 48, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        SegQueryParams q{m->view(), n, d_seg, d_dis, d_pts, d_tri};
+        hipLaunchKernelGGL(cfs_mesh_seg_kernel, dim3((n + MESH_THREADS - 1) / MESH_THREADS), dim3(MESH_THREADS), 0, nullptr, q);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(dis, d_dis, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && points) e = hipMemcpy(points, d_pts, (size_t)n * 48, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && tri) e = hipMemcpy(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = cfs_fail(CFS_ERR_HIP, "cfs_mesh_segment_distance: %s", hipGetErrorString(e));
+    (void)hipFree(d_seg); (void)hipFree(d_dis); (void)hipFree(d_pts); (void)hipFree(d_tri);
+    return rc;
+}
+
+// dist_arm_surf_200i for N poses (host arrays): d[N], linkid[N] (1-based, may be NULL), points[N x 6] (may be NULL)
+int cfs_dist_arm_mesh(const cfs_robot *robot, int njoint, int N, const double *theta, const cfs_mesh *m,
+                      double *d, int *linkid, double *points)
+{
+    if (!robot || !theta || !m || !d || N < 1) return cfs_fail(CFS_ERR_INVALID_ARG, "robot/theta/mesh/d must be given, N >= 1");
+    int rc = cfs_check_robot(robot, njoint);
+    if (rc) return rc;
+    CFS_HIPCHK(hipSetDevice(m->device));
+    DevRobot hr;
+    cfs_build_dev_robot(*robot, hr);
+    DevRobot *d_rb = nullptr;
+    double *d_th = nullptr, *d_d = nullptr, *d_pts = nullptr;
+    int *d_id = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_rb), sizeof(DevRobot));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_th), (size_t)N * njoint * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_d), (size_t)N * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_pts), (size_t)N * 48);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_id), (size_t)N * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_rb, &hr, sizeof hr, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_th, theta, (size_t)N * njoint * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        ArmMeshParams q{d_rb, m->view(), N, njoint, d_th, d_d, d_id, d_pts};
+        const int per = MESH_THREADS / njoint;
+        hipLaunchKernelGGL(cfs_dist_arm_mesh_kernel, dim3((N + per - 1) / per), dim3(MESH_THREADS), 0, nullptr, q);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(d, d_d, (size_t)N * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && linkid) e = hipMemcpy(linkid, d_id, (size_t)N * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && points) e = hipMemcpy(points, d_pts, (size_t)N * 48, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = cfs_fail(CFS_ERR_HIP, "cfs_dist_arm_mesh: %s", hipGetErrorString(e));
+    (void)hipFree(d_rb); (void)hipFree(d_th); (void)hipFree(d_d); (void)hipFree(d_pts); (void)hipFree(d_id);
+    return rc;
+}
+
+}  // extern "C"

@@ -36,8 +36,17 @@ def _ptr(a):
 
 
 def obs_to_array(obs):
-    """obs cell -> (nobs, 6) rows [obs{j}.l(:,1); obs{j}.l(:,2)]."""
-    return _f64(np.stack([np.concatenate([np.asarray(o["l"], float)[:, 0], np.asarray(o["l"], float)[:, 1]]) for o in obs]))
+    """obs cell -> (nobs, 6) rows [obs{j}.l(:,1); obs{j}.l(:,2)]; mesh obstacles (obs{j}.mesh) get a row of zeros."""
+    return _f64(np.stack([np.zeros(6) if "mesh" in o else
+                          np.concatenate([np.asarray(o["l"], float)[:, 0], np.asarray(o["l"], float)[:, 1]]) for o in obs]))
+
+
+def obs_meshes(obs):
+    """The Mesh objects of an obs cell; mesh obstacles must come after the line obstacles (cfs_problem_set_meshes)."""
+    flags = ["mesh" in o for o in obs]
+    if any(flags) and flags != sorted(flags):
+        raise ValueError("mesh obstacles must follow the line-segment obstacles in the obs cell")
+    return [o["mesh"] for o in obs if "mesh" in o]
 
 
 class CFSBatch:
@@ -86,6 +95,12 @@ class CFSBatch:
             self._h = None
 
     __del__ = close
+
+    def set_meshes(self, meshes):
+        """The last len(meshes) of the nobs obstacles are these mesh.Mesh objects from now on (cfs_problem_set_meshes)."""
+        self._meshes = list(meshes)                      # keep them alive as long as the handle uses them
+        arr = (C.c_void_p * max(len(self._meshes), 1))(*[m._h for m in self._meshes])
+        _lib.check(self._lib.cfs_problem_set_meshes(self._h, len(self._meshes), arr))
 
     # ---- whole solve ------------------------------------------------------------------------------
     def solve(self, x_init, xR1, ff, caug, obs, noise=None):
@@ -238,6 +253,9 @@ class _SolverBase:
         self.iter_O, self.total_iter, self.status = 1, 0, None
         self._batch = CFSBatch(sys_info, len(obs), [o[self.MARGIN_KEY] for o in obs], mode=self.MODE, max_batch=1,
                                device=device)
+        meshes = obs_meshes(obs)
+        if meshes:
+            self._batch.set_meshes(meshes)
 
     def _args(self):
         s = self.sys_info

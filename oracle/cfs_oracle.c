@@ -173,6 +173,8 @@ double orc_dist_lin_seg(const double *p1s, const double *p1e, const double *p2s,
 /* dist_arm_3D_Heu_2.m:23); it is restated with points(1:3), as 200i_2.m:23.  */
 /* Returns d; *linkid is 1-based, first minimum wins (strict <).               */
 /* ------------------------------------------------------------------------- */
+double orc_mesh_seg_distance(int mesh_id, const double *seg, double *points, int *tri_id);   /* mesh_oracle.c */
+
 double orc_dist_arm(const orc_robot *rb, const double *theta, int nj, const double *obs, int *linkid)
 {
     double pos[ORC_MAXLINK * 6];
@@ -187,9 +189,13 @@ double orc_dist_arm(const orc_robot *rb, const double *theta, int nj, const doub
     }
     double d = INFINITY;
     int id = 0;
+    /* Mesh obstacle (row f3; M200i/dist_arm_surf_200i.m:20-28 with the build's own point2surface_dis, see
+     * mesh_oracle.c): flagged by obs[0] = NaN, obs[1] = id given to orc_mesh_register. */
+    const int is_mesh = isnan(obs[0]);
     for (int i = 0; i < nj; ++i) {
         double pts[6];
-        double dis = orc_dist_lin_seg(pos + i * 6, pos + i * 6 + 3, obs, obs + 3, pts);
+        double dis = is_mesh ? orc_mesh_seg_distance((int)obs[1], pos + i * 6, pts, 0)
+                             : orc_dist_lin_seg(pos + i * 6, pos + i * 6 + 3, obs, obs + 3, pts);
         if (fabs(dis) < 0.0001) {                            /* :22-24 */
             double e0 = pts[0] - pos[i * 6 + 3], e1 = pts[1] - pos[i * 6 + 4], e2 = pts[2] - pos[i * 6 + 5];
             dis = -sqrt(e0 * e0 + e1 * e1 + e2 * e2);

@@ -43,8 +43,8 @@ class _Robot(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile oracle/cfs_oracle.c with gcc (building the checker is not using it)."""
-    src = os.path.join(_HERE, "cfs_oracle.c")
-    if force or (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("cfs_oracle.c", "mesh_oracle.c")]
+    if force or (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libcfs_oracle.so"])
     return _LIB_PATH
 
@@ -60,6 +60,7 @@ def lib():
         _lib.orc_dist_lin_seg.restype = C.c_double
         _lib.orc_dist_arm.restype = C.c_double
         _lib.orc_get_cost.restype = C.c_double
+        _lib.orc_mesh_seg_distance.restype = C.c_double
     return _lib
 
 
@@ -429,3 +430,24 @@ def optimizer_batch(robot, mode, H, nj, x_init, xR1, QQ, ff, caug, Aaug, Baug, l
 
 def max_threads() -> int:
     return int(lib().orc_max_threads())
+
+
+# ----------------------------------------------------------------------------------------------
+# mesh obstacles (row f3; mesh_oracle.c): brute force over every triangle, no hierarchy
+# ----------------------------------------------------------------------------------------------
+def mesh_register(mesh_id, tri):
+    """Register a (nt, 3, 3) triangle soup under id 0..15; returns the 3x2 `l` that flags the obstacle as a mesh
+    in every obs{j}.l argument of this module (l(:,1) = [NaN; id; 0], l(:,2) = 0)."""
+    tri = _f(np.asarray(tri, float).reshape(-1, 9))
+    if lib().orc_mesh_register(int(mesh_id), tri.shape[0], _p(tri)) != 0:
+        raise ValueError("mesh id outside 0..15")
+    return np.array([[np.nan, 0.0], [float(mesh_id), 0.0], [0.0, 0.0]])
+
+
+def mesh_seg_distance(mesh_id, segs):
+    """point2surface_dis for (n, 6) segments: dis (n), points (n, 6), triangle index (n)."""
+    segs = _f(np.atleast_2d(segs))
+    n = segs.shape[0]
+    dis, pts, tri = np.zeros(n), np.zeros((n, 6)), np.zeros(n, np.int32)
+    lib().orc_mesh_seg_distance_batch(int(mesh_id), n, _p(segs), _p(dis), _p(pts), _p(tri))
+    return dis, pts, tri
