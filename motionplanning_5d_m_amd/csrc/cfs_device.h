@@ -20,6 +20,8 @@ struct DevRobot {
     double base[3];
     double cap[CFS_MAX_LINKS * 6];  // cap[i*6 + k*3 + r]
     double t2l[CFS_MAX_LINKS * 3];  // 2L: translation of link i = robot.T(:,i+1)  (CapPos2.m:25)
+    double shift_bound;             // no point of the arm moves farther than this between the base pose and an evaluation point of
+                                    // num_jac: nlink * eps/2 * reach
     double prune_tol;               // a link farther than this from the base-pose minimum cannot become the minimum at any
                                     // evaluation point of num_jac (bound on the motion of any arm point: nlink*eps/2*reach)
 };

@@ -43,5 +43,13 @@ struct LinMeshParams {           // distance + literal finite-difference Jacobia
     const int *status_done;      // B, may be null: problems whose entry is non-zero have finished and are skipped
     double *dist;                // B x nmesh x H
     double *grad;                // B x nmesh x H x NJ
+    // workspace per (problem, waypoint), sizes from linearize_mesh_workspace
+    double *ends;                // [NVT][6]          end points of every link variant
+    double *upper_d;             // [NJ][nmesh]       greedy upper bound of the base-pose distance
+    double *base_d;              // [NJ][nmesh]       base-pose distance (surrogate applied; +inf: farther than any link that matters)
+    int *base_t;                 // [NJ][nmesh]       base-pose winning triangle (hierarchy order)
+    double *shift_d;             // [nmesh][NVT-NJ]   shifted-pose distances of the candidate links, +inf otherwise
+    int *near;                   // [NJ][nmesh][1+cap] count (-1: overflow) + triangles within the shift margin of the base minimum
 };
 hipError_t launch_linearize_mesh(int nj, const LinMeshParams &p, hipStream_t s);
+void linearize_mesh_workspace(int nj, int nmesh, size_t *ends, size_t *base, size_t *shift, size_t *near);

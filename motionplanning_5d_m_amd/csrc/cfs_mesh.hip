@@ -19,8 +19,11 @@
 namespace {
 
 constexpr int MESH_THREADS = 128;
-constexpr int MESH_STACK = 40;              // >= depth of the balanced hierarchy + 2 (checked at build time)
-constexpr int LEAF_TRIS = 4;
+constexpr int MESH_STACK = 24;              // >= depth of the balanced hierarchy + 2 (checked at build time)
+#ifndef CFS_LEAF_TRIS
+#define CFS_LEAF_TRIS 2
+#endif
+constexpr int LEAF_TRIS = CFS_LEAF_TRIS;
 
 // ---- device geometry -------------------------------------------------------------------------------
 __device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -164,10 +167,14 @@ __device__ void seg_tri_update(const double *P0, const double *P1, const double 
     }
 }
 
-// rigorous lower bound of dist(segment, box): the segment is covered by 4 balls of radius |d|/8, and its own
-// bounding box is at least box-box distance away; any lower bound of a cover is a lower bound of the segment
+// rigorous lower bound of dist(segment, box): the segment is covered by LB_BALLS balls of radius |d| / (2 LB_BALLS),
+// and its own bounding box is at least box-box distance away; a lower bound of a cover is a lower bound of the segment
+#ifndef CFS_LB_BALLS
+#define CFS_LB_BALLS 16
+#endif
 __device__ double node_lower_bound(const double *P0, const double *P1, const BvhNode &nd)
 {
+    constexpr int NB = CFS_LB_BALLS;
     double bb = 0.0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -178,11 +185,13 @@ __device__ double node_lower_bound(const double *P0, const double *P1, const Bvh
     bb = sqrt(bb);
     double d[3];
     sub3(P1, P0, d);
-    const double rad = sqrt(dot3(d, d)) * 0.125;
-    double sp = INFINITY;
+    const double len2 = dot3(d, d);
+    if (len2 == 0.0) return bb * (1.0 - 1e-14);              // a point: the box-box bound is the exact point-box distance
+    const double rad = sqrt(len2) * (0.5 / NB);
+    double sp2 = INFINITY;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double f = (2 * i + 1) * 0.125;
+    for (int i = 0; i < NB; ++i) {
+        const double f = (2 * i + 1) * (0.5 / NB);
         double g2 = 0.0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -190,30 +199,67 @@ __device__ double node_lower_bound(const double *P0, const double *P1, const Bvh
             const double g = fmax(0.0, fmax(nd.lo[r] - c, c - nd.hi[r]));
             g2 += g * g;
         }
-        sp = fmin(sp, sqrt(g2));
+        sp2 = fmin(sp2, g2);
     }
-    // the balls' bound loses a few ulp in rad and the square roots: shave it so that it stays a lower bound
+    const double sp = sqrt(sp2);
+    // the balls' bound loses a few ulp in rad and the square root: shave it so that it stays a lower bound
     const double spb = (sp - rad) - 1e-12 * (sp + rad);
     return fmax(bb * (1.0 - 1e-14), fmax(0.0, spb));
 }
 
-// nearest-first traversal; `stack` holds MESH_STACK ints private to the thread (LDS, strided)
+// Triangles whose distance is within `margin` of the minimum, gathered while a query runs (LDS, strided like the stack).
+// A pose shifted by less than margin/2 has its closest triangle among them, so the shifted poses of num_jac need no traversal.
+constexpr int NEAR_CAP = 12;
+struct NearList {
+    int *idx;            // [NEAR_CAP] strided
+    double *dd;          // [NEAR_CAP] strided
+    double margin;
+    int n;
+    bool over;           // more than NEAR_CAP triangles tie within the margin: the caller falls back to traversals
+};
 template <int STRIDE>
-__device__ void mesh_query(const DevMesh &m, const double *P0, const double *P1, int seed_tri, int *stack, Best &b)
+__device__ __forceinline__ void near_compact(NearList &nl, double best)
 {
-    b.d = INFINITY; b.t = INFINITY; b.tri = -1;
+    int w = 0;
+    for (int i = 0; i < nl.n; ++i)
+        if (nl.dd[i * STRIDE] <= best + nl.margin) { nl.idx[w * STRIDE] = nl.idx[i * STRIDE]; nl.dd[w * STRIDE] = nl.dd[i * STRIDE]; ++w; }
+    nl.n = w;
+}
+
+// nearest-first traversal; the thread's private stack (node, lower bound) lives in LDS, strided by STRIDE
+// `bound`: only triangles closer than this matter to the caller (b.tri stays -1 when there is none)
+template <int STRIDE, bool COLLECT>
+__device__ void mesh_query(const DevMesh &m, const double *P0, const double *P1, int seed_tri, int *stack, double *lbs, Best &b, NearList *nl,
+                           double bound = INFINITY)
+{
+    b.d = bound; b.t = INFINITY; b.tri = -1;
 #pragma unroll
     for (int r = 0; r < 6; ++r) b.pts[r] = 0.0;
     if (m.nt == 0) return;
     if (seed_tri >= 0) seg_tri_update(P0, P1, m.tri + 9 * (size_t)seed_tri, seed_tri, b);   // incumbent from a nearby query
     int sp = 0;
     int cur = 0;
-    if (node_lower_bound(P0, P1, m.nodes[0]) > b.d) return;
+    const double slack = COLLECT ? nl->margin : 0.0;        // with a collector, everything within the margin must be visited
+    if (node_lower_bound(P0, P1, m.nodes[0]) > b.d + slack) return;
     for (;;) {
         const BvhNode nd = m.nodes[cur];
         if (nd.count > 0) {
-            for (int k = nd.first; k < nd.first + nd.count; ++k)
-                if (k != seed_tri) seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, b);
+            for (int k = nd.first; k < nd.first + nd.count; ++k) {
+                if (k == seed_tri) continue;
+                if (COLLECT) {
+                    Best tb;
+                    tb.d = INFINITY; tb.t = INFINITY; tb.tri = -1;
+                    seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, tb);
+                    take(b, tb.d, tb.t, tb.pts, tb.pts + 3, k);
+                    if (!nl->over && tb.d <= b.d + nl->margin) {
+                        if (nl->n == NEAR_CAP) near_compact<STRIDE>(*nl, b.d);
+                        if (nl->n == NEAR_CAP) nl->over = true;
+                        else { nl->idx[nl->n * STRIDE] = k; nl->dd[nl->n * STRIDE] = tb.d; ++nl->n; }
+                    }
+                } else {
+                    seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, b);
+                }
+            }
             cur = -1;
         } else {
             const double ll = node_lower_bound(P0, P1, m.nodes[nd.left]);
@@ -221,15 +267,15 @@ __device__ void mesh_query(const DevMesh &m, const double *P0, const double *P1,
             const int nearc = ll <= lr ? nd.left : nd.right, farc = ll <= lr ? nd.right : nd.left;
             const double ln = fmin(ll, lr), lf = fmax(ll, lr);
             cur = -1;
-            if (ln <= b.d) {
+            if (ln <= b.d + slack) {
                 cur = nearc;
-                if (lf <= b.d && sp < MESH_STACK) stack[(sp++) * STRIDE] = farc;   // bound re-checked when popped
+                if (lf <= b.d + slack && sp < MESH_STACK) { stack[sp * STRIDE] = farc; lbs[sp * STRIDE] = lf; ++sp; }
             }
         }
         while (cur < 0) {
-            if (sp == 0) return;
-            const int c = stack[(--sp) * STRIDE];
-            if (node_lower_bound(P0, P1, m.nodes[c]) <= b.d) cur = c;
+            if (sp == 0) { if (COLLECT) near_compact<STRIDE>(*nl, b.d); return; }
+            --sp;
+            if (lbs[sp * STRIDE] <= b.d + slack) cur = stack[sp * STRIDE];   // the incumbent may have improved since the push
         }
     }
 }
@@ -240,13 +286,14 @@ struct SegQueryParams { DevMesh m; int n; const double *segs; double *dis, *pts;
 __global__ __launch_bounds__(MESH_THREADS) void cfs_mesh_seg_kernel(SegQueryParams P)
 {
     __shared__ int s_stack[MESH_STACK * MESH_THREADS];
+    __shared__ double s_lbs[MESH_STACK * MESH_THREADS];
     const int i = blockIdx.x * MESH_THREADS + threadIdx.x;
     if (i >= P.n) return;
     double seg[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) seg[r] = P.segs[(size_t)i * 6 + r];
     Best b;
-    mesh_query<MESH_THREADS>(P.m, seg, seg + 3, -1, s_stack + threadIdx.x, b);
+    mesh_query<MESH_THREADS, false>(P.m, seg, seg + 3, -1, s_stack + threadIdx.x, s_lbs + threadIdx.x, b, nullptr);
     P.dis[i] = b.d;
     if (P.pts)
 #pragma unroll
@@ -260,6 +307,7 @@ struct ArmMeshParams { const DevRobot *rb; DevMesh m; int N, nj; const double *t
 __global__ __launch_bounds__(MESH_THREADS) void cfs_dist_arm_mesh_kernel(ArmMeshParams P)
 {
     __shared__ int s_stack[MESH_STACK * MESH_THREADS];
+    __shared__ double s_lbs[MESH_STACK * MESH_THREADS];
     __shared__ double s_dis[MESH_THREADS];
     __shared__ double s_pts[MESH_THREADS * 6];
     const int nj = P.nj, per = MESH_THREADS / nj;           // poses per workgroup
@@ -278,7 +326,7 @@ __global__ __launch_bounds__(MESH_THREADS) void cfs_dist_arm_mesh_kernel(ArmMesh
         }
         link_ends(rb, k, M, e6);
         Best b;
-        mesh_query<MESH_THREADS>(P.m, e6, e6 + 3, -1, s_stack + threadIdx.x, b);
+        mesh_query<MESH_THREADS, false>(P.m, e6, e6 + 3, -1, s_stack + threadIdx.x, s_lbs + threadIdx.x, b, nullptr);
         dis = b.d;
         if (fabs(dis) < 0.0001) {                            // dist_arm_surf_200i.m:22-24
             const double qx = b.pts[0] - e6[3], qy = b.pts[1] - e6[4], qz = b.pts[2] - e6[5];
@@ -300,118 +348,195 @@ __global__ __launch_bounds__(MESH_THREADS) void cfs_dist_arm_mesh_kernel(ArmMesh
 }
 
 // Linearisation against mesh obstacles: the same scheme as cfs_fused.hip (link variants, base distances, pruned
-// candidates, minima per evaluation point of num_jac), the distance being a hierarchy query; the shifted poses
-// start from the base pose's winning triangle, so their traversals prune almost everything.
-constexpr int LM_W = 4;                                      // waypoints per workgroup
+// candidates, minima per evaluation point of num_jac), the distance being a hierarchy query.  Four kernels, every one
+// with a thread per item, so that the expensive cold traversals of the base pose fill the machine:
+//   fk     (b, waypoint, evaluation point) -> end points of every link variant
+//   upper  (b, waypoint, link, mesh)       -> greedy upper bound of the base-pose distance (one descent)
+//   base   (b, waypoint, link, mesh)       -> distance + winning triangle at the base pose, for the links that can matter
+//   shift  (b, waypoint, mesh, variant)    -> distance at the shifted poses of the links that can be the minimum there,
+//                                             started from the base pose's triangle (their traversals prune almost everything)
+//   fd     (b, waypoint, mesh)             -> minima per evaluation point, distance and literal num_jac gradient
 template <int NJ>
-__global__ __launch_bounds__(MESH_THREADS) void cfs_linearize_mesh_kernel(LinMeshParams P)
+__global__ __launch_bounds__(MESH_THREADS) void mesh_fk_kernel(LinMeshParams P)
 {
     constexpr int NS = 2 * NJ, NVT = nvt(NJ), NE = 2 * NJ + 1;
-    __shared__ int s_stack[MESH_STACK * MESH_THREADS];
-    __shared__ DevRobot s_rb;
-    __shared__ double s_sc[LM_W * NJ * 6];
-    __shared__ double s_tm[LM_W * NVT * 12];
-    __shared__ double s_en[LM_W * NVT * 6];
-    extern __shared__ __attribute__((aligned(16))) double dyn[];   // [W][NJ][nmesh] base distance, [W][nmesh][NE] minima, ints: base triangle
-    const int nmesh = P.nmesh, tid = threadIdx.x;
-    const int tiles = (P.H + LM_W - 1) / LM_W;
-    const int b = blockIdx.x / tiles, w0 = (blockIdx.x % tiles) * LM_W;
+    const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
+    if (e >= P.B * P.H * NE) return;
+    const int ev = e % NE, wp = (e / NE) % P.H, b = e / (NE * P.H);
     if (P.status_done && P.status_done[b] != 0) return;
-    const int W = min(LM_W, P.H - w0);
-    double *s_bd = dyn;
-    double *s_dv = s_bd + LM_W * NJ * nmesh;
-    int *s_bt = reinterpret_cast<int *>(s_dv + LM_W * nmesh * NE);
-    {
-        const double *src = reinterpret_cast<const double *>(P.rb);
-        double *dst = reinterpret_cast<double *>(&s_rb);
-        for (int e = tid; e < (int)(sizeof(DevRobot) / 8); e += MESH_THREADS) dst[e] = src[e];
-    }
-    __syncthreads();
-    const DevRobot *rb = &s_rb;
-    for (int e = tid; e < W * NJ * 3; e += MESH_THREADS) {
-        const int var = e % 3, m = (e / 3) % NJ, wi = e / (3 * NJ);
-        double x = P.x_[(size_t)b * P.H * NS + (size_t)(w0 + wi) * NS + m];
-        if (var == 1) x = x + FD_EPS / 2;                 // num_jac.m:11
-        else if (var == 2) x = x - FD_EPS / 2;            // num_jac.m:13
-        x = x - rb->th_off[m];                            // dist_arm_surf_200i.m:10-12 (same offset as dist_arm_3D_200i_2.m:11)
+    const DevRobot *rb = P.rb;
+    double M[12], Mn[12], e6[6];
+#pragma unroll
+    for (int k1 = 1; k1 <= NJ; ++k1) {
+        // evaluation point ev has joint m at +eps/2 if ev == 2m-1 and at -eps/2 if ev >= 2m (num_jac.m:8-14: xp is never restored)
+        double x = P.x_[((size_t)b * P.H + wp) * NS + k1 - 1];
+        if (ev == 2 * k1 - 1) x = x + FD_EPS / 2;            // num_jac.m:11
+        else if (ev >= 2 * k1) x = x - FD_EPS / 2;           // num_jac.m:13
+        x = x - rb->th_off[k1 - 1];                          // same joint offset as dist_arm_3D_200i_2.m:11
         double sn, cs;
         sincos(x, &sn, &cs);
-        s_sc[((wi * NJ + m) * 3 + var) * 2 + 0] = sn;
-        s_sc[((wi * NJ + m) * 3 + var) * 2 + 1] = cs;
-    }
-    __syncthreads();
-    for (int k1 = 1; k1 <= NJ; ++k1) {                    // link k has 2k+1 distinct transforms (see cfs_fused.hip)
-        const int nv = 2 * k1 + 1;
-        for (int e = tid; e < W * nv; e += MESH_THREADS) {
-            const int v = e % nv, wi = e / nv;
-            const int avar = (v == 2 * k1 - 1) ? 1 : (v == 2 * k1 ? 2 : 0);
-            const int pv = min(v, 2 * (k1 - 1));
-            const double sn = s_sc[((wi * NJ + (k1 - 1)) * 3 + avar) * 2 + 0];
-            const double cs = s_sc[((wi * NJ + (k1 - 1)) * 3 + avar) * 2 + 1];
-            const double *par = (k1 == 1) ? nullptr : s_tm + (wi * NVT + kvoff(k1 - 1) + pv) * 12;
-            double M[12], e6[6];
-            fk_step(rb, k1 - 1, sn, cs, par, M);
-            link_ends(rb, k1 - 1, M, e6);
-            for (int q = 0; q < 12; ++q) s_tm[(wi * NVT + kvoff(k1) + v) * 12 + q] = M[q];
-            for (int q = 0; q < 6; ++q) s_en[(wi * NVT + kvoff(k1) + v) * 6 + q] = e6[q];
-        }
-        __syncthreads();
-    }
-    // base pose: every link against every mesh
-    for (int e = tid; e < W * NJ * nmesh; e += MESH_THREADS) {
-        const int jm = e % nmesh, k0 = (e / nmesh) % NJ, wi = e / (nmesh * NJ);
-        const double *a6 = s_en + (wi * NVT + kvoff(k0 + 1)) * 6;
-        Best bq;
-        mesh_query<MESH_THREADS>(P.meshes[jm], a6, a6 + 3, -1, s_stack + tid, bq);
-        double dis = bq.d;
-        if (fabs(dis) < 0.0001) {
-            const double qx = bq.pts[0] - a6[3], qy = bq.pts[1] - a6[4], qz = bq.pts[2] - a6[5];
-            dis = -sqrt(qx * qx + qy * qy + qz * qz);
-        }
-        s_bd[(wi * NJ + k0) * nmesh + jm] = dis;
-        s_bt[(wi * NJ + k0) * nmesh + jm] = bq.tri;
-    }
-    __syncthreads();
-    for (int e = tid; e < W * nmesh; e += MESH_THREADS) {
-        const int jm = e % nmesh, wi = e / nmesh;
-        double m0 = INFINITY;
-        for (int k0 = 0; k0 < NJ; ++k0) m0 = fmin(m0, s_bd[(wi * NJ + k0) * nmesh + jm]);
-        s_dv[e * NE] = m0;
-        for (int ev = 1; ev < NE; ++ev) s_dv[e * NE + ev] = INFINITY;
-    }
-    __syncthreads();
-    // shifted poses of the links that can be the minimum there (same pruning rule and margin as cfs_fused.hip)
-    for (int e = tid; e < W * nmesh * (NVT - NJ); e += MESH_THREADS) {
-        const int sv = e % (NVT - NJ), jm = (e / (NVT - NJ)) % nmesh, wi = e / ((NVT - NJ) * nmesh);
-        int k1 = 1, v = 1;                                 // sv enumerates (link k1, variant v = 1..2 k1)
-        {
-            int acc = 0;
+        fk_step(rb, k1 - 1, sn, cs, k1 == 1 ? nullptr : M, Mn);
 #pragma unroll
-            for (int kk = 1; kk <= NJ; ++kk) { if (sv >= acc && sv < acc + 2 * kk) { k1 = kk; v = sv - acc + 1; } acc += 2 * kk; }
+        for (int q = 0; q < 12; ++q) M[q] = Mn[q];
+        if (ev <= 2 * k1) {                                  // link k1 at evaluation point ev is variant min(ev, 2 k1): stored by its owner
+            link_ends(rb, k1 - 1, M, e6);
+            double *dst = P.ends + (((size_t)b * P.H + wp) * NVT + kvoff(k1) + ev) * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) dst[q] = e6[q];
         }
-        const double bk = s_bd[(wi * NJ + k1 - 1) * nmesh + jm];
-        const double thr = fmax(s_dv[(wi * nmesh + jm) * NE], 0.0001) + rb->prune_tol;
-        if (!(bk < thr)) continue;
-        const double *a6 = s_en + (wi * NVT + kvoff(k1) + v) * 6;
+    }
+}
+
+__device__ __forceinline__ double with_surrogate(const Best &bq, const double *a6)
+{
+    double dis = bq.d;
+    if (fabs(dis) < 0.0001) {                                // dist_arm_surf_200i.m:22-24
+        const double qx = bq.pts[0] - a6[3], qy = bq.pts[1] - a6[4], qz = bq.pts[2] - a6[5];
+        dis = -sqrt(qx * qx + qy * qy + qz * qz);
+    }
+    return dis;
+}
+
+// one descent to the nearest leaf, no backtracking: an upper bound of the distance for ~2 log2(nt) box bounds
+__device__ double mesh_greedy_upper(const DevMesh &m, const double *P0, const double *P1)
+{
+    if (m.nt == 0) return INFINITY;
+    int cur = 0;
+    for (;;) {
+        const BvhNode nd = m.nodes[cur];
+        if (nd.count > 0) {
+            Best b;
+            b.d = INFINITY; b.t = INFINITY; b.tri = -1;
+            for (int k = nd.first; k < nd.first + nd.count; ++k) seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, b);
+            return b.d;
+        }
+        cur = node_lower_bound(P0, P1, m.nodes[nd.left]) <= node_lower_bound(P0, P1, m.nodes[nd.right]) ? nd.left : nd.right;
+    }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(MESH_THREADS) void mesh_upper_kernel(LinMeshParams P)
+{
+    constexpr int NVT = nvt(NJ);
+    const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
+    if (e >= P.B * P.H * NJ * P.nmesh) return;
+    const int wp = e % P.H, b = (e / P.H) % P.B, jm = (e / (P.H * P.B)) % P.nmesh, k0 = e / (P.H * P.B * P.nmesh);
+    if (P.status_done && P.status_done[b] != 0) return;
+    double a6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) a6[q] = P.ends[(((size_t)b * P.H + wp) * NVT + kvoff(k0 + 1)) * 6 + q];
+    P.upper_d[(((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm] = mesh_greedy_upper(P.meshes[jm], a6, a6 + 3);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(MESH_THREADS) void mesh_base_kernel(LinMeshParams P)
+{
+    constexpr int NVT = nvt(NJ);
+    __shared__ int s_stack[MESH_STACK * MESH_THREADS];
+    __shared__ double s_lbs[MESH_STACK * MESH_THREADS];
+    __shared__ int s_ni[NEAR_CAP * MESH_THREADS];
+    __shared__ double s_nd[NEAR_CAP * MESH_THREADS];
+    const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
+    if (e >= P.B * P.H * NJ * P.nmesh) return;
+    // link index slowest, waypoint fastest: the lanes of a wavefront hold the same link at neighbouring poses, so their
+    // traversals have similar lengths (a wavefront runs as long as its longest lane)
+    const int wp = e % P.H, b = (e / P.H) % P.B, jm = (e / (P.H * P.B)) % P.nmesh, k0 = e / (P.H * P.B * P.nmesh);
+    if (P.status_done && P.status_done[b] != 0) return;
+    double a6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) a6[q] = P.ends[(((size_t)b * P.H + wp) * NVT + kvoff(k0 + 1)) * 6 + q];
+    Best bq;
+    NearList nl;
+    nl.idx = s_ni + threadIdx.x; nl.dd = s_nd + threadIdx.x; nl.n = 0; nl.over = false;
+    nl.margin = 4.0 * P.rb->shift_bound;                    // twice what the argument needs (see NearList)
+    // Only the minimum over the links and the links within prune_tol of it matter (see mesh_shift_kernel), and the minimum
+    // is at most the smallest greedy upper bound: a link with nothing closer than `bound` is out, usually at the root.
+    const size_t o = (((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm;
+    double umin = INFINITY;
+#pragma unroll
+    for (int kk = 0; kk < NJ; ++kk) umin = fmin(umin, P.upper_d[(((size_t)b * P.H + wp) * NJ + kk) * P.nmesh + jm]);
+    const double bound = (fmax(umin, 0.0001) + P.rb->prune_tol) * (1.0 + 1e-12) + nl.margin;
+    mesh_query<MESH_THREADS, true>(P.meshes[jm], a6, a6 + 3, -1, s_stack + threadIdx.x, s_lbs + threadIdx.x, bq, &nl, bound);
+    if (bq.tri < 0) { bq.d = INFINITY; nl.n = 0; nl.over = false; }      // farther than the bound: never the minimum, never a candidate
+    P.base_d[o] = bq.tri < 0 ? INFINITY : with_surrogate(bq, a6);
+    P.base_t[o] = bq.tri;
+    // the base pose's triangle first, then the others within the margin; count < 0: too many ties, traverse instead
+    int *near = P.near + o * (NEAR_CAP + 1);
+    near[0] = nl.over ? -1 : nl.n;
+    for (int i = 0; i < nl.n; ++i) near[1 + i] = nl.idx[i * MESH_THREADS];
+}
+
+template <int NJ>
+__global__ __launch_bounds__(MESH_THREADS) void mesh_shift_kernel(LinMeshParams P)
+{
+    constexpr int NVT = nvt(NJ), NSV = NVT - NJ;
+    __shared__ int s_stack[MESH_STACK * MESH_THREADS];
+    __shared__ double s_lbs[MESH_STACK * MESH_THREADS];
+    const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
+    if (e >= P.B * P.H * P.nmesh * NSV) return;
+    const int wp = e % P.H, b = (e / P.H) % P.B, jm = (e / (P.H * P.B)) % P.nmesh, sv = e / (P.H * P.B * P.nmesh);   // variant slowest (see base)
+    if (P.status_done && P.status_done[b] != 0) return;
+    int k1 = 1, v = 1;                                       // sv enumerates (link k1, variant v = 1..2 k1)
+    {
+        int acc = 0;
+#pragma unroll
+        for (int kk = 1; kk <= NJ; ++kk) { if (sv >= acc && sv < acc + 2 * kk) { k1 = kk; v = sv - acc + 1; } acc += 2 * kk; }
+    }
+    const size_t bo = (((size_t)b * P.H + wp) * NJ) * P.nmesh + jm;
+    double m0 = INFINITY;
+#pragma unroll
+    for (int k0 = 0; k0 < NJ; ++k0) m0 = fmin(m0, P.base_d[bo + (size_t)k0 * P.nmesh]);
+    // a link farther than prune_tol above max(min, 1e-4) cannot be the minimum nor reach the surrogate at a shifted pose
+    const double thr = fmax(m0, 0.0001) + P.rb->prune_tol;
+    double out = INFINITY;
+    if (P.base_d[bo + (size_t)(k1 - 1) * P.nmesh] < thr) {
+        double a6[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a6[q] = P.ends[(((size_t)b * P.H + wp) * NVT + kvoff(k1) + v) * 6 + q];
         Best bq;
-        mesh_query<MESH_THREADS>(P.meshes[jm], a6, a6 + 3, s_bt[(wi * NJ + k1 - 1) * nmesh + jm], s_stack + tid, bq);
-        double dis = bq.d;
-        if (fabs(dis) < 0.0001) {
-            const double qx = bq.pts[0] - a6[3], qy = bq.pts[1] - a6[4], qz = bq.pts[2] - a6[5];
-            dis = -sqrt(qx * qx + qy * qy + qz * qz);
+        const size_t ob = bo + (size_t)(k1 - 1) * P.nmesh;
+        const int *near = P.near + ob * (NEAR_CAP + 1);
+        const int nn_ = near[0];
+        if (nn_ >= 0) {                                      // the pose moved by < margin/2: its closest triangle is on the list
+            const DevMesh &m = P.meshes[jm];
+            bq.d = INFINITY; bq.t = INFINITY; bq.tri = -1;
+            for (int i = 0; i < nn_; ++i) { const int k = near[1 + i]; seg_tri_update(a6, a6 + 3, m.tri + 9 * (size_t)k, k, bq); }
+        } else {
+            mesh_query<MESH_THREADS, false>(P.meshes[jm], a6, a6 + 3, P.base_t[ob], s_stack + threadIdx.x, s_lbs + threadIdx.x, bq, nullptr);
         }
-        double *dv = s_dv + (wi * nmesh + jm) * NE;
-        const int evhi = (v == 2 * k1) ? NE - 1 : v;
-        for (int ev = v; ev <= evhi; ++ev) __hip_atomic_fetch_min(dv + ev, dis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        out = with_surrogate(bq, a6);
     }
-    __syncthreads();
-    for (int e = tid; e < W * nmesh; e += MESH_THREADS) {
-        const int jm = e % nmesh, wi = e / nmesh;
-        const double *dv = s_dv + e * NE;
-        const size_t o = ((size_t)b * nmesh + jm) * P.H + w0 + wi;
-        P.dist[o] = dv[0];
-        for (int m = 0; m < NJ; ++m) P.grad[o * NJ + m] = (dv[2 * m + 1] - dv[2 * m + 2]) / FD_EPS;   // num_jac.m:14
+    P.shift_d[(((size_t)b * P.H + wp) * P.nmesh + jm) * NSV + sv] = out;   // +inf: not a candidate
+}
+
+template <int NJ>
+__global__ __launch_bounds__(MESH_THREADS) void mesh_fd_kernel(LinMeshParams P)
+{
+    constexpr int NVT = nvt(NJ), NSV = NVT - NJ, NE = 2 * NJ + 1;
+    const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
+    if (e >= P.B * P.H * P.nmesh) return;
+    const int jm = e % P.nmesh, wp = (e / P.nmesh) % P.H, b = e / (P.nmesh * P.H);
+    if (P.status_done && P.status_done[b] != 0) return;
+    const size_t bo = (((size_t)b * P.H + wp) * NJ) * P.nmesh + jm;
+    const double *sh = P.shift_d + (((size_t)b * P.H + wp) * P.nmesh + jm) * NSV;
+    double dev[NE];
+    dev[0] = INFINITY;
+#pragma unroll
+    for (int k0 = 0; k0 < NJ; ++k0) dev[0] = fmin(dev[0], P.base_d[bo + (size_t)k0 * P.nmesh]);
+#pragma unroll
+    for (int ev = 1; ev < NE; ++ev) {
+        double d = INFINITY;
+#pragma unroll
+        for (int k1 = 1; k1 <= NJ; ++k1) {
+            const double dis = sh[k1 * (k1 - 1) + min(ev, 2 * k1) - 1];   // variants of link k1 start at sum_{k<k1} 2k = k1 (k1-1)
+            if (dis < d) d = dis;
+        }
+        dev[ev] = d;
     }
+    const size_t o = ((size_t)b * P.nmesh + jm) * P.H + wp;
+    P.dist[o] = dev[0];
+#pragma unroll
+    for (int m = 0; m < NJ; ++m) P.grad[o * NJ + m] = (dev[2 * m + 1] - dev[2 * m + 2]) / FD_EPS;   // num_jac.m:14
 }
 
 // ---- host: hierarchy ------------------------------------------------------------------------------------
@@ -489,20 +614,40 @@ int upload_mesh(const std::vector<double> &tri9, cfs_mesh **out)
 
 }  // namespace
 
+template <int NJ>
+static hipError_t launch_linearize_mesh_nj(const LinMeshParams &p, hipStream_t s)
+{
+    constexpr int NVT = nvt(NJ), NE = 2 * NJ + 1;
+    const dim3 block(MESH_THREADS);
+    auto blocks = [](size_t n) { return dim3((unsigned)((n + MESH_THREADS - 1) / MESH_THREADS)); };
+    const size_t bh = (size_t)p.B * p.H;
+    hipLaunchKernelGGL(mesh_fk_kernel<NJ>, blocks(bh * NE), block, 0, s, p);
+    hipLaunchKernelGGL(mesh_upper_kernel<NJ>, blocks(bh * NJ * p.nmesh), block, 0, s, p);
+    hipLaunchKernelGGL(mesh_base_kernel<NJ>, blocks(bh * NJ * p.nmesh), block, 0, s, p);
+    hipLaunchKernelGGL(mesh_shift_kernel<NJ>, blocks(bh * p.nmesh * (NVT - NJ)), block, 0, s, p);
+    hipLaunchKernelGGL(mesh_fd_kernel<NJ>, blocks(bh * p.nmesh), block, 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_linearize_mesh(int nj, const LinMeshParams &p, hipStream_t s)
 {
-    const int tiles = (p.H + LM_W - 1) / LM_W, NE = 2 * nj + 1;
-    const size_t dynb = ((size_t)LM_W * nj * p.nmesh + (size_t)LM_W * p.nmesh * NE) * 8 + (size_t)LM_W * nj * p.nmesh * 4 + 16;
-    const dim3 grid(p.B * tiles), block(MESH_THREADS);
     switch (nj) {
-    case 2: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<2>, grid, block, dynb, s, p); break;
-    case 3: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<3>, grid, block, dynb, s, p); break;
-    case 4: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<4>, grid, block, dynb, s, p); break;
-    case 5: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<5>, grid, block, dynb, s, p); break;
-    case 6: hipLaunchKernelGGL(cfs_linearize_mesh_kernel<6>, grid, block, dynb, s, p); break;
+    case 2: return launch_linearize_mesh_nj<2>(p, s);
+    case 3: return launch_linearize_mesh_nj<3>(p, s);
+    case 4: return launch_linearize_mesh_nj<4>(p, s);
+    case 5: return launch_linearize_mesh_nj<5>(p, s);
+    case 6: return launch_linearize_mesh_nj<6>(p, s);
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+}
+
+// doubles / ints of workspace per (problem, waypoint) the pipeline needs
+void linearize_mesh_workspace(int nj, int nmesh, size_t *ends, size_t *base, size_t *shift, size_t *near)
+{
+    *ends = (size_t)nvt(nj) * 6;
+    *base = (size_t)nj * nmesh;
+    *shift = (size_t)nmesh * (nvt(nj) - nj);
+    *near = (size_t)nj * nmesh * (NEAR_CAP + 1);
 }
 
 extern "C" {

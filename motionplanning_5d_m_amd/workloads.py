@@ -99,3 +99,21 @@ def config4(route_wp, B=4096, seed=20260104, H=40, sigma=0.02):
     batch = SimpleNamespace(B=B, nobs=2, x0=x0, xg=xg, x_init=x_init, xR1=xR1, ff=ff, caug=caug, obs=obs, noise=None,
                             margin_cfs=np.full(2, 0.2), margin_psg=np.full(2, 0.2))
     return s, batch
+
+
+def config5(B=256, seed=20260105, H=50, n_tri=10000, margin=0.12):
+    """BASELINE config 5 (mesh map, 50 waypoints, 256 seeds), synthetic: the reference's assembly-line map is an STL
+    file that cannot travel (map/assembly line_Assem1.STL, 27 396 triangles, mm) and its distance function is missing
+    from the reference, so the map is ``mesh.assembly_line`` (about n_tri triangles, metres, around the M200i base) and
+    the single obstacle is that mesh.  Start / goal draws as config 3.  Returns (family, batch, triangles)."""
+    from .mesh import assembly_line
+    s = _family(H, FANUC_Qp, 50.0)
+    rng = np.random.default_rng(seed)
+    x0 = X0C + rng.uniform(-0.1, 0.1, (B, 5))
+    xg = X0C * np.array([-1.0, 1, 1, 1, 1]) + rng.uniform(-0.1, 0.1, (B, 5))
+    noise = 0.1 * rng.standard_normal((B, 20, H * 5))
+    x_init, xR1, ff, caug = _batch_terms(s, x0, xg)
+    tri = assembly_line(s.robot.base, n_target=n_tri, seed=seed)
+    batch = SimpleNamespace(B=B, nobs=1, x0=x0, xg=xg, x_init=x_init, xR1=xR1, ff=ff, caug=caug, obs=np.zeros((B, 1, 6)),
+                            noise=noise, margin_cfs=np.full(1, margin), margin_psg=np.full(1, margin))
+    return s, batch, tri
