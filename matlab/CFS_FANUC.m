@@ -11,7 +11,7 @@ classdef CFS_FANUC
        end
        function self = optimizer(self)                            % one MEX call instead of the MATLAB loop
             [self.u, self.x_, c, ec, eu, self.iter_O, self.total_iter, self.status] = ...
-                cfs_mex(0, self.obs, self.sys_info, self.ROBOT, []);
+                cfs_mex('solve', 0, self.obs, self.sys_info, self.ROBOT, []);
             n = self.iter_O - 1;
             self.eval.cost_all = c(1:n)'; self.eval.e_cost_all = ec(1:n)'; self.eval.e_u_all = eu(1:n)';
             if n > 0, self.eval.cost_new = c(n); end

@@ -11,7 +11,7 @@ classdef PSGCFS_FANUC
        end
        function self = optimizer(self)                            % one MEX call instead of the MATLAB loop
             [self.u, self.x_, c, ec, eu, self.iter_O, self.total_iter, self.status] = ...
-                cfs_mex(1, self.obs, self.sys_info, self.ROBOT, 0.1*randn(self.nn, self.sys_info.MAX_O_ITER));
+                cfs_mex('solve', 1, self.obs, self.sys_info, self.ROBOT, 0.1*randn(self.nn, self.sys_info.MAX_O_ITER));
             n = self.iter_O - 1;
             self.eval.cost_all = c(1:n)'; self.eval.e_cost_all = ec(1:n)'; self.eval.e_u_all = eu(1:n)';
             if n > 0, self.eval.cost_new = c(n); end
