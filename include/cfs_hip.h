@@ -235,6 +235,16 @@ int cfs_dist_arm_mesh(const cfs_robot *robot, int njoint, int N, const double *t
  * The meshes must outlive the solves. */
 int cfs_problem_set_meshes(cfs_problem *p, int nmesh, const cfs_mesh *const *meshes);
 
+/* ---- CHOMP_FANUC ----------------------------------------------------------
+ * self = CHOMP_FANUC(obs_, sys_info, uref, ROBOT); self = self.optimizer()  (Lib/CHOMP_FANUC.m:34-69) for B problems of
+ * the handle's family (robot, H, QQ, alpha, epsilon_O, MAX_O_ITER; create it in CFS mode).  HOST pointers.
+ * in: x_init, xR1, ff, caug, obs as for cfs_solve_batch (noise unused); u0: B x nn = uref; D, epsilon: nobs =
+ * obs_{j+1}.D / .epsilon.  out: u, x_, cost_all / e_cost_all / e_u_all (B x MAX_O_ITER), iter_O; total_iter (0) and
+ * status may be NULL.  The update is the reference's, literally (step 3*alpha, gradient rows Baug((i-1)*njoint+1:
+ * i*njoint,:), dm_f without the M200i joint offset, derivest derivatives): see csrc/cfs_chomp.hip for the list. */
+int cfs_chomp_batch(cfs_problem *p, const cfs_batch_in *in, const double *u0, const double *D, const double *epsilon,
+                    const cfs_batch_out *out);
+
 #ifdef __cplusplus
 }
 #endif

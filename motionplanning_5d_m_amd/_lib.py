@@ -122,6 +122,7 @@ SYMBOLS = [
     ("cfs_mesh_segment_distance", C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     ("cfs_dist_arm_mesh", C.c_int, [C.POINTER(cfs_robot), C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     ("cfs_problem_set_meshes", C.c_int, [_P, C.c_int, _P]),
+    ("cfs_chomp_batch", C.c_int, [_P, C.POINTER(cfs_batch_in), _P, _P, _P, C.POINTER(cfs_batch_out)]),
 ]
 
 _lib = None

@@ -646,6 +646,42 @@ int cfs_build_terms_device(cfs_problem *p, int B, const double *x0, const double
     return CFS_SUCCESS;
 }
 
+int cfs_chomp_batch(cfs_problem *p, const cfs_batch_in *in, const double *u0, const double *D, const double *epsilon,
+                    const cfs_batch_out *out)
+{
+    if (!p || !in || !out || !u0 || !D || !epsilon) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    const int B = in->B;
+    if (B < 1 || B > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "B=%d outside 1..max_batch=%d", B, p->d.max_batch);
+    if (!in->x_init || !in->xR1 || !in->ff || !in->caug || !in->obs) return fail(CFS_ERR_INVALID_ARG, "NULL input array");
+    if (!out->u || !out->x_ || !out->cost_all || !out->e_cost_all || !out->e_u_all || !out->iter_O) return fail(CFS_ERR_INVALID_ARG, "NULL output array");
+    if (p->nmesh > 0) return fail(CFS_ERR_INVALID_ARG, "CHOMP_FANUC measures line obstacles only (Lib/CHOMP_FANUC.m:119)");
+    if (!chomp_fits(p->d.njoint, p->d.H, p->d.nobs)) return fail(CFS_ERR_INVALID_ARG, "H x nobs too large for the CHOMP kernel's 64 KB of LDS");
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nn = p->nn, nx = p->nx, ns = p->ns, K = p->d.MAX_O_ITER, nobs = p->d.nobs;
+    Stage st;
+    ChompParams c;
+    memset(&c, 0, sizeof c);
+    c.rb = p->rb.p; c.B = B; c.H = p->d.H; c.nobs = p->d.nobs; c.max_o_iter = p->d.MAX_O_ITER;
+    c.dt = p->d.robot.delta_t; c.alpha = p->d.alpha; c.epsilon_O = p->d.epsilon_O; c.QQ = p->QQ.p;
+    c.x_init = st.up(in->x_init, B * nx); c.xR1 = st.up(in->xR1, B * ns); c.ff = st.up(in->ff, B * nn); c.caug = st.up(in->caug, B);
+    c.obs = st.up(in->obs, B * nobs * 6); c.u0 = st.up(u0, B * nn); c.D = st.up(D, nobs); c.eps = st.up(epsilon, nobs);
+    c.u = st.up<double>(nullptr, B * nn); c.x_ = st.up<double>(nullptr, B * nx);
+    c.cost_all = st.up<double>(nullptr, B * std::max<size_t>(K, 1)); c.e_cost_all = st.up<double>(nullptr, B * std::max<size_t>(K, 1));
+    c.e_u_all = st.up<double>(nullptr, B * std::max<size_t>(K, 1));
+    c.iter_O = st.up<int>(nullptr, B); c.total_iter = st.up<int>(nullptr, B); c.status = st.up<int>(nullptr, B);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    HIPCHK(hipMemset(c.cost_all, 0, B * std::max<size_t>(K, 1) * 8)); HIPCHK(hipMemset(c.e_cost_all, 0, B * std::max<size_t>(K, 1) * 8));
+    HIPCHK(hipMemset(c.e_u_all, 0, B * std::max<size_t>(K, 1) * 8));
+    chomp_derivest_tables(c);
+    HIPCHK(launch_chomp(p->d.njoint, c, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    st.down(out->u, c.u, B * nn); st.down(out->x_, c.x_, B * nx);
+    st.down(out->cost_all, c.cost_all, B * K); st.down(out->e_cost_all, c.e_cost_all, B * K); st.down(out->e_u_all, c.e_u_all, B * K);
+    st.down(out->iter_O, c.iter_O, B); st.down(out->total_iter, c.total_iter, B); st.down(out->status, c.status, B);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
 int cfs_problem_set_meshes(cfs_problem *p, int nmesh, const cfs_mesh *const *meshes)
 {
     if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");

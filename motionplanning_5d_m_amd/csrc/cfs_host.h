@@ -53,3 +53,19 @@ struct LinMeshParams {           // distance + literal finite-difference Jacobia
 };
 hipError_t launch_linearize_mesh(int nj, const LinMeshParams &p, hipStream_t s);
 void linearize_mesh_workspace(int nj, int nmesh, size_t *ends, size_t *base, size_t *shift, size_t *near);
+
+// ---- CHOMP_FANUC (cfs_chomp.hip) -----------------------------------------------------------------------
+struct ChompParams {
+    const DevRobot *rb;
+    int B, H, nobs, max_o_iter;
+    double dt, alpha, epsilon_O;
+    const double *QQ;                                    // nn x nn column-major
+    const double *x_init, *xR1, *ff, *caug, *obs, *u0;   // per problem: H*ns, ns, nn, 1, nobs*6, nn
+    const double *D, *eps;                               // nobs: obs{j}.D, obs{j}.epsilon
+    double *u, *x_, *cost_all, *e_cost_all, *e_u_all;
+    int *iter_O, *total_iter, *status;
+    double delta[26], fdarule[2], rmat[12], pinv[12], cov_scale;   // derivest's constant tables (chomp_derivest_tables)
+};
+hipError_t launch_chomp(int nj, const ChompParams &p, hipStream_t s);
+void chomp_derivest_tables(ChompParams &p);
+bool chomp_fits(int nj, int H, int nobs);

@@ -153,6 +153,26 @@ class CFSBatch:
         _lib.check(self._lib.cfs_solve_batch_device(self._h, C.byref(i), C.byref(o), C.c_void_p(stream)))
         return out
 
+    # ---- CHOMP (row f4) ------------------------------------------------------------------------------------
+    def chomp(self, x_init, xR1, ff, caug, obs, u0, D, epsilon):
+        """CHOMP_FANUC.optimizer() for B problems (cfs_chomp_batch); host arrays in and out."""
+        x_init, xR1, ff, caug, obs, u0 = _f64(x_init), _f64(xR1), _f64(ff), _f64(caug).reshape(-1), _f64(obs), _f64(u0)
+        D, epsilon = _f64(np.asarray(D, float).reshape(-1)), _f64(np.asarray(epsilon, float).reshape(-1))
+        B = x_init.shape[0]
+        assert x_init.shape == (B, self.nx) and u0.shape == (B, self.nn) and obs.shape == (B, self.nobs, 6)
+        assert D.size == self.nobs and epsilon.size == self.nobs
+        i = _lib.cfs_batch_in()
+        i.B = B
+        i.x_init, i.xR1, i.ff, i.caug, i.obs = _ptr(x_init), _ptr(xR1), _ptr(ff), _ptr(caug), _ptr(obs)
+        r = SimpleNamespace(u=np.zeros((B, self.nn)), x_=np.zeros((B, self.nx)), cost_all=np.zeros((B, self.K)),
+                            e_cost_all=np.zeros((B, self.K)), e_u_all=np.zeros((B, self.K)),
+                            iter_O=np.zeros(B, np.int32), total_iter=np.zeros(B, np.int32), status=np.zeros(B, np.int32))
+        o = _lib.cfs_batch_out()
+        o.u, o.x_, o.cost_all, o.e_cost_all, o.e_u_all = _ptr(r.u), _ptr(r.x_), _ptr(r.cost_all), _ptr(r.e_cost_all), _ptr(r.e_u_all)
+        o.iter_O, o.total_iter, o.status = _ptr(r.iter_O), _ptr(r.total_iter), _ptr(r.status)
+        _lib.check(self._lib.cfs_chomp_batch(self._h, C.byref(i), _ptr(u0), _ptr(D), _ptr(epsilon), C.byref(o)))
+        return r
+
     # ---- per-problem setup on the device (row f2) ------------------------------------------------------
     def set_state_cost(self, Qaug):
         """The drivers' state-cost matrix Qaug (main_FANUC.m:79-84), once per handle."""
@@ -295,3 +315,35 @@ class PSGCFS_FANUC(_SolverBase):
     """Lib/PSGCFS_FANUC.m -- margin obs{j}.D, noisy gradient step + projection.  The normrnd draws
     (PSGCFS_FANUC.m:109) are passed in explicitly: optimizer(noise=(rows, nn) array of N(0, 0.1^2))."""
     MODE, MARGIN_KEY = "PSGCFS", "D"
+
+
+class CHOMP_FANUC:
+    """Lib/CHOMP_FANUC.m -- ``CHOMP_FANUC(obs_, sys_info, uref, ROBOT).optimizer()``.  ``obs_`` is the reference's cell:
+    ``obs_[0] = dict(num_obs=n)`` followed by the n obstacles (``l``, ``D``, ``epsilon``) (M16iB/CHOMP.m:26-29)."""
+
+    def __init__(self, obs, sys_info, uu, ROBOT="M16iB", device=None):
+        self.obs, self.sys_info, self.ROBOT = obs, sys_info, ROBOT
+        if getattr(sys_info.robot, "name", ROBOT) != ROBOT:
+            raise ValueError(f"sys_info.robot is {sys_info.robot.name!r} but ROBOT={ROBOT!r}")
+        n = int(obs[0]["num_obs"])
+        self._obstacles = list(obs[1:1 + n])
+        self.nn = sys_info.H * sys_info.nu
+        self.x_ = np.asarray(sys_info.x_, float).reshape(-1).copy()
+        self.u = np.asarray(uu, float).reshape(-1).copy()
+        self.eval = EVAL(sys_info)
+        self.iter_O, self.total_iter = 1, 0
+        self._batch = CFSBatch(sys_info, n, [o["epsilon"] for o in self._obstacles], mode="CFS", max_batch=1, device=device)
+
+    def optimizer(self):
+        s = self.sys_info
+        xR1 = np.asarray(s.xR, float).reshape(s.nstate, -1)[:, 0]
+        r = self._batch.chomp(np.asarray(s.x_, float).reshape(1, -1), xR1[None], _f64(s.ff).reshape(1, -1), np.array([s.caug], float),
+                              obs_to_array(self._obstacles)[None], self.u[None], [o["D"] for o in self._obstacles],
+                              [o["epsilon"] for o in self._obstacles])
+        n = int(r.iter_O[0]) - 1
+        self.u, self.x_, self.iter_O = r.u[0], r.x_[0], int(r.iter_O[0])
+        self.eval.cost_all, self.eval.e_cost_all, self.eval.e_u_all = r.cost_all[0, :n], r.e_cost_all[0, :n], r.e_u_all[0, :n]
+        if n > 0:
+            self.eval.cost_new = float(r.cost_all[0, n - 1])
+        print("MAX_ITER")  # EVAL.m:70 (the loop never converges by distance: eval.x_ is not refreshed)
+        return self

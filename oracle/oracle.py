@@ -43,7 +43,7 @@ class _Robot(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile oracle/cfs_oracle.c with gcc (building the checker is not using it)."""
-    srcs = [os.path.join(_HERE, f) for f in ("cfs_oracle.c", "mesh_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("cfs_oracle.c", "mesh_oracle.c", "chomp_oracle.c")]
     if force or (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libcfs_oracle.so"])
     return _LIB_PATH
@@ -61,6 +61,8 @@ def lib():
         _lib.orc_dist_arm.restype = C.c_double
         _lib.orc_get_cost.restype = C.c_double
         _lib.orc_mesh_seg_distance.restype = C.c_double
+        _lib.orc_derivest.restype = C.c_double
+        _lib.orc_chomp_fobs.restype = C.c_double
     return _lib
 
 
@@ -451,3 +453,45 @@ def mesh_seg_distance(mesh_id, segs):
     dis, pts, tri = np.zeros(n), np.zeros((n, 6)), np.zeros(n, np.int32)
     lib().orc_mesh_seg_distance_batch(int(mesh_id), n, _p(segs), _p(dis), _p(pts), _p(tri))
     return dis, pts, tri
+
+
+# ----------------------------------------------------------------------------------------------
+# CHOMP_FANUC (row f4; chomp_oracle.c)
+# ----------------------------------------------------------------------------------------------
+_DERIVEST_FUN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
+
+
+def derivest(fun, x0):
+    """derivest(fun, x0, 'Vectorized','no') with the suite's defaults (DERIVESTsuite/derivest.m): (der, errest)."""
+    tab = (C.c_double * 64)()
+    lib().orc_derivest_setup(tab)
+    cb = _DERIVEST_FUN(lambda x, _ctx: float(fun(x)))
+    err = C.c_double(0)
+    return lib().orc_derivest(tab, cb, None, C.c_double(float(x0)), C.byref(err)), err.value
+
+
+def chomp_dm(robot, theta, obs_l, D):
+    """dm_f (CHOMP_FANUC.m:105-126): per-link distance minus D, without the M200i joint offset."""
+    rb, th = c_robot(robot), _f(theta)
+    o = _f(np.concatenate([np.asarray(obs_l, float)[:, 0], np.asarray(obs_l, float)[:, 1]]))
+    d = np.zeros(th.size)
+    lib().orc_chomp_dm(C.byref(rb), C.c_int(th.size), _p(th), _p(o), C.c_double(D), _p(d))
+    return d
+
+
+def chomp_optimizer(ROBOT, sys_info, obs, uref):
+    """CHOMP_FANUC(obs_, sys_info, uref, ROBOT).optimizer(); obs = list of dict(l, D, epsilon) (the cell without its header)."""
+    s = sys_info
+    rb = c_robot(s.robot)
+    H, nj = s.H, s.njoint
+    nn, nx, K = H * nj, H * 2 * nj, s.MAX_O_ITER
+    u, x_ = np.zeros(nn), np.zeros(nx)
+    cost_all, e_cost_all, e_u_all = np.zeros(K), np.zeros(K), np.zeros(K)
+    D, eps = _f([o["D"] for o in obs]), _f([o["epsilon"] for o in obs])
+    it = lib().orc_chomp_optimizer(
+        C.byref(rb), C.c_int(H), C.c_int(nj), C.c_double(s.robot.delta_t), _p(_f(s.x_)), _p(_f(s.xR1)), _p(_f(uref)),
+        _p(np.asfortranarray(s.QQ)), _p(_f(s.ff)), C.c_double(s.caug), _p(np.asfortranarray(s.Baug)), C.c_int(len(obs)),
+        _p(obs_array(obs)), _p(D), _p(eps), C.c_double(s.epsilon_O), C.c_int(K), C.c_double(s.alpha), _p(u), _p(x_),
+        _p(cost_all), _p(e_cost_all), _p(e_u_all))
+    n = it - 1
+    return SimpleNamespace(u=u, x_=x_, iter_O=it, cost_all=cost_all[:n], e_cost_all=e_cost_all[:n], e_u_all=e_u_all[:n])
