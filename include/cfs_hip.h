@@ -157,6 +157,11 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
 int cfs_set_state_cost(cfs_problem *p, const double *Qaug);
 int cfs_build_terms_device(cfs_problem *p, int B, const double *x0, const double *xg,
                            double *x_init, double *xR1, double *ff, double *caug, void *stream);
+/* The same from B RRT routes (RRTstar_CFS.m:94-110): routes is B x nwp x njoint (DEVICE; per problem the 5 x nwp route_wp as
+ * MATLAB stores it); x_init = cubicpolytraj(route, (0:nwp-1)*delta_t, linspace(0,(nwp-1)*delta_t,H+1)) with zero waypoint
+ * velocities (its default), waypoint 0 dropped, zero velocities; x0 / xg = the route's ends. */
+int cfs_build_terms_from_routes_device(cfs_problem *p, int B, const double *routes, int nwp,
+                                       double *x_init, double *xR1, double *ff, double *caug, void *stream);
 
 /* ---- measurement ------------------------------------------------------------------------------
  * When enabled, cfs_solve_batch_device brackets each kernel launch with hipEvents recorded on the

@@ -109,6 +109,7 @@ SYMBOLS = [
     ("cfs_solve_batch_device", C.c_int, [_P, C.POINTER(cfs_batch_in), C.POINTER(cfs_batch_out), _P]),
     ("cfs_set_state_cost", C.c_int, [_P, _P]),
     ("cfs_build_terms_device", C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    ("cfs_build_terms_from_routes_device", C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P]),
     ("cfs_profile_enable", C.c_int, [_P, C.c_int]),
     ("cfs_profile_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("cfs_dist_arm", C.c_int, [C.POINTER(cfs_robot), C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),

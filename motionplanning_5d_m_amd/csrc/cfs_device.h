@@ -189,6 +189,9 @@ struct TermsParams {             // per-problem line reference and cost terms fr
     const double *F1, *F2;       // nn x nj column-major: Baug'*Qaug*Aaug(:,1:nj), Baug'*Qaug*G
     const double *Cq;            // 2nj x 2nj column-major: E'*Qaug*E, E = [Aaug(:,1:nj), -G]
     const double *x0, *xg;       // B x nj
+    const double *route;         // optional, B x nwp x nj (waypoint-major): x0 / xg are its ends, x_init its cubic resampling
+    int nwp;
+    double dt;
     double *x_init, *xR1, *ff, *caug;
 };
 void launch_build_terms(const TermsParams &p, hipStream_t s);

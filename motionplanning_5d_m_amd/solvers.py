@@ -192,6 +192,19 @@ class CFSBatch:
                                                     C.c_void_p(stream)))
         return x_init, xR1, ff, caug
 
+    def build_terms_from_routes_device(self, routes, stream=None):
+        """(x_init, xR1, ff, caug) for B RRT routes given as a CUDA tensor (B, nwp, njoint): cubic zero-velocity
+        resampling to H+1 samples + cost terms, on the device (RRTstar_CFS.m:94-110, 159-163)."""
+        B, nwp = routes.shape[0], routes.shape[1]
+        assert routes.is_cuda and routes.dtype == torch.float64 and routes.is_contiguous() and routes.shape[2] == self.nj
+        z = lambda *sh: torch.empty(*sh, dtype=torch.float64, device=routes.device)  # noqa: E731
+        x_init, xR1, ff, caug = z(B, self.nx), z(B, self.ns), z(B, self.nn), z(B)
+        if stream is None:
+            stream = torch.cuda.current_stream(routes.device).cuda_stream
+        _lib.check(self._lib.cfs_build_terms_from_routes_device(self._h, B, _ptr(routes), nwp, _ptr(x_init), _ptr(xR1), _ptr(ff),
+                                                                _ptr(caug), C.c_void_p(stream)))
+        return x_init, xR1, ff, caug
+
     # ---- measurement ------------------------------------------------------------------------------
     def profile(self, on=True):
         _lib.check(self._lib.cfs_profile_enable(self._h, 1 if on else 0))
