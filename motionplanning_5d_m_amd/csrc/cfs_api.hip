@@ -159,8 +159,8 @@ struct cfs_problem {
     // mesh obstacles (cfs_problem_set_meshes): the last nmesh of the nobs obstacles
     int nmesh = 0;
     DevBuf<DevMesh> meshes_d;
-    DevBuf<double> st_cost, m_ends, m_base, m_shift, m_upper;
-    DevBuf<int> st_done, m_tri, m_near;
+    DevBuf<double> st_cost, m_ends, m_base, m_shift, m_upper, m_pd, m_pnd;
+    DevBuf<int> st_done, m_tri, m_near, m_pi;
     bool prof = false;
     std::vector<hipEvent_t> ev;   // 4 per profiled solve: gemm start/stop, fused start/stop
     void release_all()
@@ -176,6 +176,7 @@ struct cfs_problem {
         Yg.release(); Tg.release(); qp_status.release(); qp_iter.release(); noise_row.release();
         linkid.release(); done.release(); meshes_d.release(); st_cost.release(); st_done.release();
         m_ends.release(); m_base.release(); m_shift.release(); m_tri.release(); m_near.release(); m_upper.release();
+        m_pd.release(); m_pnd.release(); m_pi.release();
     }
 };
 
@@ -514,7 +515,7 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
         LinMeshParams lm;
         lm.rb = p->rb.p; lm.B = B; lm.H = p->d.H; lm.nmesh = p->nmesh; lm.meshes = p->meshes_d.p;
         lm.dist = p->dist.p; lm.grad = p->grad.p;
-        lm.ends = p->m_ends.p; lm.base_d = p->m_base.p; lm.upper_d = p->m_upper.p; lm.base_t = p->m_tri.p; lm.shift_d = p->m_shift.p; lm.near = p->m_near.p;
+        lm.ends = p->m_ends.p; lm.base_d = p->m_base.p; lm.upper_d = p->m_upper.p; lm.base_t = p->m_tri.p; lm.shift_d = p->m_shift.p; lm.near = p->m_near.p; lm.piece_d = p->m_pd.p; lm.piece_i = p->m_pi.p; lm.piece_nd = p->m_pnd.p;
         fp.nmesh = p->nmesh; fp.ext_dist = p->dist.p; fp.ext_grad = p->grad.p; fp.max_launch_iters = 1;
         fp.st_qu = p->qu.p; fp.st_cost = p->st_cost.p; fp.st_noise = p->noise_row.p; fp.st_done = p->st_done.p;
         for (int it = 0; it < std::max(K, 1); ++it) {
@@ -713,12 +714,14 @@ int cfs_problem_set_meshes(cfs_problem *p, int nmesh, const cfs_mesh *const *mes
     }
     p->meshes_d.release(); p->st_cost.release(); p->st_done.release();
     p->m_ends.release(); p->m_base.release(); p->m_shift.release(); p->m_tri.release(); p->m_near.release(); p->m_upper.release();
+    p->m_pd.release(); p->m_pnd.release(); p->m_pi.release();
     p->nmesh = 0;
     if (nmesh > 0) {
-        size_t we, wb, ws, wn;
-        linearize_mesh_workspace(p->d.njoint, nmesh, &we, &wb, &ws, &wn);
+        size_t we, wb, ws, wn, wpd, wpi, wpn;
+        linearize_mesh_workspace(p->d.njoint, nmesh, &we, &wb, &ws, &wn, &wpd, &wpi, &wpn);
         const size_t bh = (size_t)p->d.max_batch * p->d.H;
         HIPCHK(p->m_ends.alloc(bh * we)); HIPCHK(p->m_base.alloc(bh * wb)); HIPCHK(p->m_upper.alloc(bh * wb)); HIPCHK(p->m_tri.alloc(bh * wb)); HIPCHK(p->m_shift.alloc(bh * ws)); HIPCHK(p->m_near.alloc(bh * wn));
+        HIPCHK(p->m_pd.alloc(bh * wpd)); HIPCHK(p->m_pi.alloc(bh * wpi)); HIPCHK(p->m_pnd.alloc(bh * wpn));
         HIPCHK(p->meshes_d.alloc(nmesh));
         HIPCHK(p->st_cost.alloc(2 * (size_t)p->d.max_batch));
         HIPCHK(p->st_done.alloc(p->d.max_batch));

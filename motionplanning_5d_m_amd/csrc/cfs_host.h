@@ -15,10 +15,10 @@ void cfs_build_dev_robot(const cfs_robot &r, DevRobot &d);
     } while (0)
 
 // ---- mesh obstacles (cfs_mesh.hip) --------------------------------------------------------------
-struct BvhNode {                 // 64 B; leaf when count > 0
-    double lo[3], hi[3];
-    int left, right;             // children (inner nodes)
-    int first, count;            // triangles [first, first + count) of the leaf, in BVH order
+struct BvhNode {                 // 128 B = one L2 line: an inner node carries the boxes of BOTH children, so a level costs one
+    double lo[2][3], hi[2][3];   // dependent load; an empty child has lo = +inf, hi = -inf (its lower bound is +inf)
+    int child[2];                // >= 0: inner node index; < 0: leaf, -(first * 8 + count) - 1, triangles [first, first + count) in BVH order
+    int pad[2];
 };
 struct DevMesh {                 // device view of one mesh
     const BvhNode *nodes;
@@ -50,9 +50,12 @@ struct LinMeshParams {           // distance + literal finite-difference Jacobia
     int *base_t;                 // [NJ][nmesh]       base-pose winning triangle (hierarchy order)
     double *shift_d;             // [nmesh][NVT-NJ]   shifted-pose distances of the candidate links, +inf otherwise
     int *near;                   // [NJ][nmesh][1+cap] count (-1: overflow) + triangles within the shift margin of the base minimum
+    double *piece_d, *piece_nd;  // per piece of a link axis: record / near-list distances (sizes from linearize_mesh_workspace)
+    int *piece_i;
 };
 hipError_t launch_linearize_mesh(int nj, const LinMeshParams &p, hipStream_t s);
-void linearize_mesh_workspace(int nj, int nmesh, size_t *ends, size_t *base, size_t *shift, size_t *near);
+void linearize_mesh_workspace(int nj, int nmesh, size_t *ends, size_t *base, size_t *shift, size_t *near, size_t *piece_d, size_t *piece_i,
+                              size_t *piece_nd);
 
 // ---- CHOMP_FANUC (cfs_chomp.hip) -----------------------------------------------------------------------
 struct ChompParams {

@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int MESH_THREADS = 128;
-constexpr int MESH_STACK = 24;              // >= depth of the balanced hierarchy + 2 (checked at build time)
+constexpr int MESH_STACK = 20;              // >= depth of the balanced hierarchy + 2 (checked at build time)
 #ifndef CFS_LEAF_TRIS
 #define CFS_LEAF_TRIS 2
 #endif
@@ -170,16 +170,16 @@ __device__ void seg_tri_update(const double *P0, const double *P1, const double 
 // rigorous lower bound of dist(segment, box): the segment is covered by LB_BALLS balls of radius |d| / (2 LB_BALLS),
 // and its own bounding box is at least box-box distance away; a lower bound of a cover is a lower bound of the segment
 #ifndef CFS_LB_BALLS
-#define CFS_LB_BALLS 16
+#define CFS_LB_BALLS 4
 #endif
-__device__ double node_lower_bound(const double *P0, const double *P1, const BvhNode &nd)
+__device__ double node_lower_bound(const double *P0, const double *P1, const double *blo, const double *bhi)
 {
     constexpr int NB = CFS_LB_BALLS;
     double bb = 0.0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const double lo = fmin(P0[r], P1[r]), hi = fmax(P0[r], P1[r]);
-        const double g = fmax(0.0, fmax(nd.lo[r] - hi, lo - nd.hi[r]));
+        const double g = fmax(0.0, fmax(blo[r] - hi, lo - bhi[r]));
         bb += g * g;
     }
     bb = sqrt(bb);
@@ -196,7 +196,7 @@ __device__ double node_lower_bound(const double *P0, const double *P1, const Bvh
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double c = P0[r] + f * d[r];
-            const double g = fmax(0.0, fmax(nd.lo[r] - c, c - nd.hi[r]));
+            const double g = fmax(0.0, fmax(blo[r] - c, c - bhi[r]));
             g2 += g * g;
         }
         sp2 = fmin(sp2, g2);
@@ -212,7 +212,7 @@ __device__ double node_lower_bound(const double *P0, const double *P1, const Bvh
 constexpr int NEAR_CAP = 12;
 struct NearList {
     int *idx;            // [NEAR_CAP] strided
-    double *dd;          // [NEAR_CAP] strided
+    float *dd;           // [NEAR_CAP] strided, distances rounded DOWN (an entry is never dropped wrongly, at worst kept needlessly)
     double margin;
     int n;
     bool over;           // more than NEAR_CAP triangles tie within the margin: the caller falls back to traversals
@@ -222,14 +222,14 @@ __device__ __forceinline__ void near_compact(NearList &nl, double best)
 {
     int w = 0;
     for (int i = 0; i < nl.n; ++i)
-        if (nl.dd[i * STRIDE] <= best + nl.margin) { nl.idx[w * STRIDE] = nl.idx[i * STRIDE]; nl.dd[w * STRIDE] = nl.dd[i * STRIDE]; ++w; }
+        if ((double)nl.dd[i * STRIDE] <= best + nl.margin) { nl.idx[w * STRIDE] = nl.idx[i * STRIDE]; nl.dd[w * STRIDE] = nl.dd[i * STRIDE]; ++w; }
     nl.n = w;
 }
 
 // nearest-first traversal; the thread's private stack (node, lower bound) lives in LDS, strided by STRIDE
 // `bound`: only triangles closer than this matter to the caller (b.tri stays -1 when there is none)
 template <int STRIDE, bool COLLECT>
-__device__ void mesh_query(const DevMesh &m, const double *P0, const double *P1, int seed_tri, int *stack, double *lbs, Best &b, NearList *nl,
+__device__ void mesh_query(const DevMesh &m, const double *P0, const double *P1, int seed_tri, int *stack, float *lbs, Best &b, NearList *nl,
                            double bound = INFINITY)
 {
     b.d = bound; b.t = INFINITY; b.tri = -1;
@@ -238,13 +238,12 @@ __device__ void mesh_query(const DevMesh &m, const double *P0, const double *P1,
     if (m.nt == 0) return;
     if (seed_tri >= 0) seg_tri_update(P0, P1, m.tri + 9 * (size_t)seed_tri, seed_tri, b);   // incumbent from a nearby query
     int sp = 0;
-    int cur = 0;
+    int cur = 0;                                            // the root is always an inner node (upload_mesh)
     const double slack = COLLECT ? nl->margin : 0.0;        // with a collector, everything within the margin must be visited
-    if (node_lower_bound(P0, P1, m.nodes[0]) > b.d + slack) return;
     for (;;) {
-        const BvhNode nd = m.nodes[cur];
-        if (nd.count > 0) {
-            for (int k = nd.first; k < nd.first + nd.count; ++k) {
+        if (cur < 0) {                                      // leaf
+            const int code = -(cur + 1), first = code >> 3, count = code & 7;
+            for (int k = first; k < first + count; ++k) {
                 if (k == seed_tri) continue;
                 if (COLLECT) {
                     Best tb;
@@ -254,28 +253,29 @@ __device__ void mesh_query(const DevMesh &m, const double *P0, const double *P1,
                     if (!nl->over && tb.d <= b.d + nl->margin) {
                         if (nl->n == NEAR_CAP) near_compact<STRIDE>(*nl, b.d);
                         if (nl->n == NEAR_CAP) nl->over = true;
-                        else { nl->idx[nl->n * STRIDE] = k; nl->dd[nl->n * STRIDE] = tb.d; ++nl->n; }
+                        else { nl->idx[nl->n * STRIDE] = k; nl->dd[nl->n * STRIDE] = __double2float_rd(tb.d); ++nl->n; }
                     }
                 } else {
                     seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, b);
                 }
             }
-            cur = -1;
+            cur = 0x7fffffff;
         } else {
-            const double ll = node_lower_bound(P0, P1, m.nodes[nd.left]);
-            const double lr = node_lower_bound(P0, P1, m.nodes[nd.right]);
-            const int nearc = ll <= lr ? nd.left : nd.right, farc = ll <= lr ? nd.right : nd.left;
+            const BvhNode nd = m.nodes[cur];                // one load: both children's boxes
+            const double ll = node_lower_bound(P0, P1, nd.lo[0], nd.hi[0]);
+            const double lr = node_lower_bound(P0, P1, nd.lo[1], nd.hi[1]);
+            const int nearc = ll <= lr ? nd.child[0] : nd.child[1], farc = ll <= lr ? nd.child[1] : nd.child[0];
             const double ln = fmin(ll, lr), lf = fmax(ll, lr);
-            cur = -1;
+            cur = 0x7fffffff;
             if (ln <= b.d + slack) {
                 cur = nearc;
-                if (lf <= b.d + slack && sp < MESH_STACK) { stack[sp * STRIDE] = farc; lbs[sp * STRIDE] = lf; ++sp; }
+                if (lf <= b.d + slack && sp < MESH_STACK) { stack[sp * STRIDE] = farc; lbs[sp * STRIDE] = __double2float_rd(lf); ++sp; }
             }
         }
-        while (cur < 0) {
+        while (cur == 0x7fffffff) {
             if (sp == 0) { if (COLLECT) near_compact<STRIDE>(*nl, b.d); return; }
             --sp;
-            if (lbs[sp * STRIDE] <= b.d + slack) cur = stack[sp * STRIDE];   // the incumbent may have improved since the push
+            if ((double)lbs[sp * STRIDE] <= b.d + slack) cur = stack[sp * STRIDE];   // the incumbent may have improved since the push
         }
     }
 }
@@ -286,7 +286,7 @@ struct SegQueryParams { DevMesh m; int n; const double *segs; double *dis, *pts;
 __global__ __launch_bounds__(MESH_THREADS) void cfs_mesh_seg_kernel(SegQueryParams P)
 {
     __shared__ int s_stack[MESH_STACK * MESH_THREADS];
-    __shared__ double s_lbs[MESH_STACK * MESH_THREADS];
+    __shared__ float s_lbs[MESH_STACK * MESH_THREADS];
     const int i = blockIdx.x * MESH_THREADS + threadIdx.x;
     if (i >= P.n) return;
     double seg[6];
@@ -307,7 +307,7 @@ struct ArmMeshParams { const DevRobot *rb; DevMesh m; int N, nj; const double *t
 __global__ __launch_bounds__(MESH_THREADS) void cfs_dist_arm_mesh_kernel(ArmMeshParams P)
 {
     __shared__ int s_stack[MESH_STACK * MESH_THREADS];
-    __shared__ double s_lbs[MESH_STACK * MESH_THREADS];
+    __shared__ float s_lbs[MESH_STACK * MESH_THREADS];
     __shared__ double s_dis[MESH_THREADS];
     __shared__ double s_pts[MESH_THREADS * 6];
     const int nj = P.nj, per = MESH_THREADS / nj;           // poses per workgroup
@@ -352,7 +352,8 @@ __global__ __launch_bounds__(MESH_THREADS) void cfs_dist_arm_mesh_kernel(ArmMesh
 // with a thread per item, so that the expensive cold traversals of the base pose fill the machine:
 //   fk     (b, waypoint, evaluation point) -> end points of every link variant
 //   upper  (b, waypoint, link, mesh)       -> greedy upper bound of the base-pose distance (one descent)
-//   base   (b, waypoint, link, mesh)       -> distance + winning triangle at the base pose, for the links that can matter
+//   base   (b, waypoint, link, mesh, piece)-> distance + winning triangle at the base pose per quarter of the link axis, for what can matter
+//   reduce (b, waypoint, link, mesh)       -> the link's minimum over its pieces, surrogate, merged near-tie list
 //   shift  (b, waypoint, mesh, variant)    -> distance at the shifted poses of the links that can be the minimum there,
 //                                             started from the base pose's triangle (their traversals prune almost everything)
 //   fd     (b, waypoint, mesh)             -> minima per evaluation point, distance and literal num_jac gradient
@@ -403,19 +404,20 @@ __device__ double mesh_greedy_upper(const DevMesh &m, const double *P0, const do
     if (m.nt == 0) return INFINITY;
     int cur = 0;
     for (;;) {
-        const BvhNode nd = m.nodes[cur];
-        if (nd.count > 0) {
+        if (cur < 0) {
+            const int code = -(cur + 1), first = code >> 3, count = code & 7;
             Best b;
             b.d = INFINITY; b.t = INFINITY; b.tri = -1;
-            for (int k = nd.first; k < nd.first + nd.count; ++k) seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, b);
+            for (int k = first; k < first + count; ++k) seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, b);
             return b.d;
         }
-        cur = node_lower_bound(P0, P1, m.nodes[nd.left]) <= node_lower_bound(P0, P1, m.nodes[nd.right]) ? nd.left : nd.right;
+        const BvhNode nd = m.nodes[cur];
+        cur = node_lower_bound(P0, P1, nd.lo[0], nd.hi[0]) <= node_lower_bound(P0, P1, nd.lo[1], nd.hi[1]) ? nd.child[0] : nd.child[1];
     }
 }
 
 template <int NJ>
-__global__ __launch_bounds__(MESH_THREADS) void mesh_upper_kernel(LinMeshParams P)
+__global__ __launch_bounds__(MESH_THREADS, 2) void mesh_upper_kernel(LinMeshParams P)
 {
     constexpr int NVT = nvt(NJ);
     const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
@@ -428,50 +430,118 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_upper_kernel(LinMeshParams 
     P.upper_d[(((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm] = mesh_greedy_upper(P.meshes[jm], a6, a6 + 3);
 }
 
+// A link axis is queried in MESH_PIECES equal pieces, each on its own lane: a piece is covered by smaller balls (tighter
+// node bounds, shorter traversals), the pieces far from the surface die at the root against the common bound, and there
+// are MESH_PIECES times more lanes to fill the machine with.  dist(link, T) = min over the pieces of dist(piece, T).
+#ifndef CFS_MESH_PIECES
+#define CFS_MESH_PIECES 4
+#endif
+constexpr int MESH_PIECES = CFS_MESH_PIECES;
+constexpr int PIECE_D = 5;                                   // per piece: raw distance, parameter along the whole axis, closest point on the axis
+constexpr int PIECE_I = 2 + NEAR_CAP;                        // winning triangle, near count (-1: overflow), near triangles
+
 template <int NJ>
-__global__ __launch_bounds__(MESH_THREADS) void mesh_base_kernel(LinMeshParams P)
+__global__ __launch_bounds__(MESH_THREADS, 2) void mesh_base_kernel(LinMeshParams P)
 {
     constexpr int NVT = nvt(NJ);
     __shared__ int s_stack[MESH_STACK * MESH_THREADS];
-    __shared__ double s_lbs[MESH_STACK * MESH_THREADS];
+    __shared__ float s_lbs[MESH_STACK * MESH_THREADS];
     __shared__ int s_ni[NEAR_CAP * MESH_THREADS];
-    __shared__ double s_nd[NEAR_CAP * MESH_THREADS];
+    __shared__ float s_nd[NEAR_CAP * MESH_THREADS];
     const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
-    if (e >= P.B * P.H * NJ * P.nmesh) return;
-    // link index slowest, waypoint fastest: the lanes of a wavefront hold the same link at neighbouring poses, so their
-    // traversals have similar lengths (a wavefront runs as long as its longest lane)
-    const int wp = e % P.H, b = (e / P.H) % P.B, jm = (e / (P.H * P.B)) % P.nmesh, k0 = e / (P.H * P.B * P.nmesh);
+    if (e >= P.B * P.H * NJ * P.nmesh * MESH_PIECES) return;
+    // piece and link index slowest, waypoint fastest: the lanes of a wavefront hold the same piece of the same link at
+    // neighbouring poses, so their traversals have similar lengths (a wavefront runs as long as its longest lane)
+    const int wp = e % P.H, b = (e / P.H) % P.B, jm = (e / (P.H * P.B)) % P.nmesh, k0 = (e / (P.H * P.B * P.nmesh)) % NJ;
+    const int pc = e / (P.H * P.B * P.nmesh * NJ);
     if (P.status_done && P.status_done[b] != 0) return;
-    double a6[6];
+    const size_t o = (((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm;
+    double *rec = P.piece_d + (o * MESH_PIECES + pc) * PIECE_D;
+    int *reci = P.piece_i + (o * MESH_PIECES + pc) * PIECE_I;
+    double *recn = P.piece_nd + (o * MESH_PIECES + pc) * NEAR_CAP;
+    double a6[6], d[3];
 #pragma unroll
     for (int q = 0; q < 6; ++q) a6[q] = P.ends[(((size_t)b * P.H + wp) * NVT + kvoff(k0 + 1)) * 6 + q];
+    sub3(a6 + 3, a6, d);
+    const bool point = dot3(d, d) == 0.0;                    // M200i links 1 and 3 are points: one "piece"
+    rec[0] = INFINITY; rec[1] = INFINITY; rec[2] = rec[3] = rec[4] = 0.0; reci[0] = -1; reci[1] = 0;
+    if (point && pc > 0) return;
+    double s6[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        s6[r] = point || pc == 0 ? a6[r] : a6[r] + ((double)pc / MESH_PIECES) * d[r];
+        s6[3 + r] = point || pc == MESH_PIECES - 1 ? a6[3 + r] : a6[r] + ((double)(pc + 1) / MESH_PIECES) * d[r];
+    }
     Best bq;
     NearList nl;
     nl.idx = s_ni + threadIdx.x; nl.dd = s_nd + threadIdx.x; nl.n = 0; nl.over = false;
     nl.margin = 4.0 * P.rb->shift_bound;                    // twice what the argument needs (see NearList)
     // Only the minimum over the links and the links within prune_tol of it matter (see mesh_shift_kernel), and the minimum
-    // is at most the smallest greedy upper bound: a link with nothing closer than `bound` is out, usually at the root.
-    const size_t o = (((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm;
+    // is at most the smallest greedy upper bound: a piece with nothing closer than `bound` is out, usually at the root.
     double umin = INFINITY;
 #pragma unroll
     for (int kk = 0; kk < NJ; ++kk) umin = fmin(umin, P.upper_d[(((size_t)b * P.H + wp) * NJ + kk) * P.nmesh + jm]);
     const double bound = (fmax(umin, 0.0001) + P.rb->prune_tol) * (1.0 + 1e-12) + nl.margin;
-    mesh_query<MESH_THREADS, true>(P.meshes[jm], a6, a6 + 3, -1, s_stack + threadIdx.x, s_lbs + threadIdx.x, bq, &nl, bound);
-    if (bq.tri < 0) { bq.d = INFINITY; nl.n = 0; nl.over = false; }      // farther than the bound: never the minimum, never a candidate
-    P.base_d[o] = bq.tri < 0 ? INFINITY : with_surrogate(bq, a6);
-    P.base_t[o] = bq.tri;
-    // the base pose's triangle first, then the others within the margin; count < 0: too many ties, traverse instead
+    mesh_query<MESH_THREADS, true>(P.meshes[jm], s6, s6 + 3, -1, s_stack + threadIdx.x, s_lbs + threadIdx.x, bq, &nl, bound);
+    if (bq.tri < 0) return;                                  // nothing within the bound
+    rec[0] = bq.d;
+    rec[1] = point ? 0.0 : ((double)pc + bq.t) / MESH_PIECES;
+    rec[2] = bq.pts[0]; rec[3] = bq.pts[1]; rec[4] = bq.pts[2];
+    reci[0] = bq.tri;
+    reci[1] = nl.over ? -1 : nl.n;
+    for (int i = 0; i < nl.n; ++i) { reci[2 + i] = nl.idx[i * MESH_THREADS]; recn[i] = (double)nl.dd[i * MESH_THREADS]; }
+}
+
+// pieces -> link: lexicographic minimum (distance, parameter), surrogate, and the union of the pieces' near lists
+template <int NJ>
+__global__ __launch_bounds__(MESH_THREADS) void mesh_reduce_kernel(LinMeshParams P)
+{
+    constexpr int NVT = nvt(NJ);
+    const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
+    if (e >= P.B * P.H * NJ * P.nmesh) return;
+    const int jm = e % P.nmesh, k0 = (e / P.nmesh) % NJ, wp = (e / (P.nmesh * NJ)) % P.H, b = e / (P.nmesh * NJ * P.H);
+    if (P.status_done && P.status_done[b] != 0) return;
+    const size_t o = (((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm;
+    Best bq;
+    bq.d = INFINITY; bq.t = INFINITY; bq.tri = -1;
+    for (int pc = 0; pc < MESH_PIECES; ++pc) {
+        const double *rec = P.piece_d + (o * MESH_PIECES + pc) * PIECE_D;
+        const int tri = P.piece_i[(o * MESH_PIECES + pc) * PIECE_I];
+        if (tri >= 0) take(bq, rec[0], rec[1], rec + 2, rec + 2, tri);
+    }
     int *near = P.near + o * (NEAR_CAP + 1);
-    near[0] = nl.over ? -1 : nl.n;
-    for (int i = 0; i < nl.n; ++i) near[1 + i] = nl.idx[i * MESH_THREADS];
+    if (bq.tri < 0) { P.base_d[o] = INFINITY; P.base_t[o] = -1; near[0] = 0; return; }   // farther than the bound: never the minimum, never a candidate
+    const double *a6 = P.ends + (((size_t)b * P.H + wp) * NVT + kvoff(k0 + 1)) * 6;
+    P.base_d[o] = with_surrogate(bq, a6);
+    P.base_t[o] = bq.tri;
+    const double lim = bq.d + 4.0 * P.rb->shift_bound;
+    int n = 0;
+    bool over = false;
+    for (int pc = 0; pc < MESH_PIECES && !over; ++pc) {
+        const int *reci = P.piece_i + (o * MESH_PIECES + pc) * PIECE_I;
+        const double *recn = P.piece_nd + (o * MESH_PIECES + pc) * NEAR_CAP;
+        if (reci[0] < 0) continue;
+        // a piece whose own minimum is beyond the limit contributes nothing, whatever its list says
+        if (P.piece_d[(o * MESH_PIECES + pc) * PIECE_D] > lim) continue;
+        if (reci[1] < 0) { over = true; break; }
+        for (int i = 0; i < reci[1]; ++i) {
+            if (recn[i] > lim) continue;
+            bool dup = false;
+            for (int w = 0; w < n; ++w) dup = dup || near[1 + w] == reci[2 + i];
+            if (dup) continue;
+            if (n == NEAR_CAP) { over = true; break; }
+            near[1 + n++] = reci[2 + i];
+        }
+    }
+    near[0] = over ? -1 : n;                                 // < 0: too many ties, the shifted poses traverse instead
 }
 
 template <int NJ>
-__global__ __launch_bounds__(MESH_THREADS) void mesh_shift_kernel(LinMeshParams P)
+__global__ __launch_bounds__(MESH_THREADS, 2) void mesh_shift_kernel(LinMeshParams P)
 {
     constexpr int NVT = nvt(NJ), NSV = NVT - NJ;
     __shared__ int s_stack[MESH_STACK * MESH_THREADS];
-    __shared__ double s_lbs[MESH_STACK * MESH_THREADS];
+    __shared__ float s_lbs[MESH_STACK * MESH_THREADS];
     const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
     if (e >= P.B * P.H * P.nmesh * NSV) return;
     const int wp = e % P.H, b = (e / P.H) % P.B, jm = (e / (P.H * P.B)) % P.nmesh, sv = e / (P.H * P.B * P.nmesh);   // variant slowest (see base)
@@ -547,29 +617,30 @@ struct Builder {
     std::vector<BvhNode> nodes;
     int depth = 0;
 
-    int build(int first, int count, int level)
+    // builds the subtree of triangles [first, first + count); returns its reference (inner node index, or leaf code < 0) and box
+    int build(int first, int count, int level, double *lo, double *hi)
     {
         depth = std::max(depth, level);
-        const int id = (int)nodes.size();
-        nodes.emplace_back();
-        BvhNode nd;
-        for (int r = 0; r < 3; ++r) { nd.lo[r] = INFINITY; nd.hi[r] = -INFINITY; }
         double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int r = 0; r < 3; ++r) { lo[r] = INFINITY; hi[r] = -INFINITY; }
         for (int i = first; i < first + count; ++i) {
             const double *T = tri + 9 * (size_t)order[i];
             for (int v = 0; v < 3; ++v)
-                for (int r = 0; r < 3; ++r) { nd.lo[r] = std::min(nd.lo[r], T[3 * v + r]); nd.hi[r] = std::max(nd.hi[r], T[3 * v + r]); }
+                for (int r = 0; r < 3; ++r) { lo[r] = std::min(lo[r], T[3 * v + r]); hi[r] = std::max(hi[r], T[3 * v + r]); }
             for (int r = 0; r < 3; ++r) { clo[r] = std::min(clo[r], cen[3 * (size_t)order[i] + r]); chi[r] = std::max(chi[r], cen[3 * (size_t)order[i] + r]); }
         }
-        nd.left = nd.right = -1; nd.first = first; nd.count = 0;
-        if (count <= LEAF_TRIS) { nd.count = count; nodes[id] = nd; return id; }
+        if (count <= LEAF_TRIS) return -(first * 8 + count) - 1;
+        const int id = (int)nodes.size();
+        nodes.emplace_back();
         int ax = 0;
         for (int r = 1; r < 3; ++r) if (chi[r] - clo[r] > chi[ax] - clo[ax]) ax = r;
         const int mid = first + count / 2;                    // median split: balanced, depth <= ceil(log2(nt)) + 1
         std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
                          [&](int a, int c) { const double ca = cen[3 * (size_t)a + ax], cc = cen[3 * (size_t)c + ax]; return ca < cc || (ca == cc && a < c); });
-        nd.left = build(first, mid - first, level + 1);
-        nd.right = build(mid, first + count - mid, level + 1);
+        BvhNode nd;
+        memset(&nd, 0, sizeof nd);
+        nd.child[0] = build(first, mid - first, level + 1, nd.lo[0], nd.hi[0]);
+        nd.child[1] = build(mid, first + count - mid, level + 1, nd.lo[1], nd.hi[1]);
         nodes[id] = nd;
         return id;
     }
@@ -587,7 +658,16 @@ int upload_mesh(const std::vector<double> &tri9, cfs_mesh **out)
     for (int i = 0; i < nt; ++i)
         for (int r = 0; r < 3; ++r) bd.cen[3 * (size_t)i + r] = (tri9[9 * (size_t)i + r] + tri9[9 * (size_t)i + 3 + r] + tri9[9 * (size_t)i + 6 + r]) / 3.0;
     bd.nodes.reserve(2 * (size_t)nt / LEAF_TRIS + 8);
-    bd.build(0, nt, 1);
+    double rlo[3], rhi[3];
+    if (nt > (1 << 27)) return cfs_fail(CFS_ERR_INVALID_ARG, "mesh too large (%d triangles)", nt);
+    const int root = bd.build(0, nt, 1, rlo, rhi);
+    if (root < 0) {                                          // a mesh that is one leaf: give it an inner root with an empty second child
+        BvhNode nd;
+        memset(&nd, 0, sizeof nd);
+        for (int r = 0; r < 3; ++r) { nd.lo[0][r] = rlo[r]; nd.hi[0][r] = rhi[r]; nd.lo[1][r] = INFINITY; nd.hi[1][r] = -INFINITY; }
+        nd.child[0] = root; nd.child[1] = -1;                // -1 = leaf code of zero triangles
+        bd.nodes.push_back(nd);
+    }
     if (bd.depth + 2 > MESH_STACK) return cfs_fail(CFS_ERR_INVALID_ARG, "mesh hierarchy too deep (%d levels)", bd.depth);
     std::vector<double> tri_o(9 * (size_t)nt);
     for (int i = 0; i < nt; ++i) memcpy(&tri_o[9 * (size_t)i], &tri9[9 * (size_t)bd.order[i]], 72);
@@ -595,7 +675,7 @@ int upload_mesh(const std::vector<double> &tri9, cfs_mesh **out)
     if (!m) return cfs_fail(CFS_ERR_ALLOC, "out of host memory");
     m->device = cfs_current_device();
     m->nt = nt; m->nnodes = (int)bd.nodes.size(); m->depth = bd.depth;
-    for (int r = 0; r < 3; ++r) { m->bbox[r] = bd.nodes[0].lo[r]; m->bbox[3 + r] = bd.nodes[0].hi[r]; }
+    for (int r = 0; r < 3; ++r) { m->bbox[r] = rlo[r]; m->bbox[3 + r] = rhi[r]; }
     hipError_t e = hipSetDevice(m->device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->nodes_d), bd.nodes.size() * sizeof(BvhNode));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->tri_d), tri_o.size() * 8);
@@ -623,7 +703,8 @@ static hipError_t launch_linearize_mesh_nj(const LinMeshParams &p, hipStream_t s
     const size_t bh = (size_t)p.B * p.H;
     hipLaunchKernelGGL(mesh_fk_kernel<NJ>, blocks(bh * NE), block, 0, s, p);
     hipLaunchKernelGGL(mesh_upper_kernel<NJ>, blocks(bh * NJ * p.nmesh), block, 0, s, p);
-    hipLaunchKernelGGL(mesh_base_kernel<NJ>, blocks(bh * NJ * p.nmesh), block, 0, s, p);
+    hipLaunchKernelGGL(mesh_base_kernel<NJ>, blocks(bh * NJ * p.nmesh * MESH_PIECES), block, 0, s, p);
+    hipLaunchKernelGGL(mesh_reduce_kernel<NJ>, blocks(bh * NJ * p.nmesh), block, 0, s, p);
     hipLaunchKernelGGL(mesh_shift_kernel<NJ>, blocks(bh * p.nmesh * (NVT - NJ)), block, 0, s, p);
     hipLaunchKernelGGL(mesh_fd_kernel<NJ>, blocks(bh * p.nmesh), block, 0, s, p);
     return hipGetLastError();
@@ -642,12 +723,16 @@ hipError_t launch_linearize_mesh(int nj, const LinMeshParams &p, hipStream_t s)
 }
 
 // doubles / ints of workspace per (problem, waypoint) the pipeline needs
-void linearize_mesh_workspace(int nj, int nmesh, size_t *ends, size_t *base, size_t *shift, size_t *near)
+void linearize_mesh_workspace(int nj, int nmesh, size_t *ends, size_t *base, size_t *shift, size_t *near, size_t *piece_d, size_t *piece_i,
+                              size_t *piece_nd)
 {
     *ends = (size_t)nvt(nj) * 6;
     *base = (size_t)nj * nmesh;
     *shift = (size_t)nmesh * (nvt(nj) - nj);
     *near = (size_t)nj * nmesh * (NEAR_CAP + 1);
+    *piece_d = (size_t)nj * nmesh * MESH_PIECES * PIECE_D;
+    *piece_i = (size_t)nj * nmesh * MESH_PIECES * PIECE_I;
+    *piece_nd = (size_t)nj * nmesh * MESH_PIECES * NEAR_CAP;
 }
 
 extern "C" {
