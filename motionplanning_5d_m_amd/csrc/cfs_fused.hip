@@ -114,6 +114,19 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid)
     return t;
 }
 
+// four sums through one exchange
+__device__ __forceinline__ void block_sum4(double &a, double &b, double &c, double &d, double *red, int tid)
+{
+    const double sa = wave_add(a), sb = wave_add(b), sc = wave_add(c), sd = wave_add(d);
+    __syncthreads();
+    if ((tid & 63) == 0) { const int w = tid >> 6; red[w] = sa; red[4 + w] = sb; red[8 + w] = sc; red[12 + w] = sd; }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+    c = (red[8] + red[9]) + (red[10] + red[11]);
+    d = (red[12] + red[13]) + (red[14] + red[15]);
+}
+
 // inclusive prefix sum over the 64 lanes of a wavefront (DPP row shifts + row broadcasts)
 __device__ __forceinline__ double wave_scan_incl(double v)
 {
@@ -570,10 +583,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     p2 += rs_ * rs_;
                     p3 += xs[HN + k] * xs[HN + k];
                 }
-                p0 = block_sum(p0, red, tid);
-                p1 = block_sum(p1, red, tid);
-                p2 = block_sum(p2, red, tid);
-                p3 = block_sum(p3, red, tid);
+                block_sum4(p0, p1, p2, p3, red, tid);
                 const double lmax = P.mode == CFS_MODE_CFS ? 1.0 / P.alpha : 1.0;
                 const double ru = sqrt(p0) + sqrt(p1), rs = sqrt(p2) + sqrt(p3);
                 fbound = 1.0001 * 0.5 * fmin(lmax * ru * ru, P.lmax_vel * rs * rs);
@@ -809,8 +819,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             s_x[i * NS + c] = th;
             s_x[i * NS + NJ + c] = om;
         }
-        du2 = block_sum(du2, red, tid);
-        dx2 = block_sum(dx2, red, tid);
+        { double z0 = 0.0, z1 = 0.0; block_sum4(du2, dx2, z0, z1, red, tid); }
         for (int k = tid; k < HN; k += FT) s_u[k] = xs[k];
         __syncthreads();
         // cost = 0.5*u'*QQ*u + ff'*u + caug (EVAL.m:52).  CFS: the stop test does not depend on it, so u is
