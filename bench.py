@@ -50,7 +50,7 @@ def main():
                          "one is measured too (shorter) and reported under 'other_mode'")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=16,
                     help="independent solves in flight (one handle + HIP stream each); 1 = strictly serial steps")
     ap.add_argument("--no-other-mode", action="store_true", help="measure only --mode (profiling runs)")
     args = ap.parse_args()
