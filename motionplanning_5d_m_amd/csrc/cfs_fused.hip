@@ -931,10 +931,13 @@ hipError_t CFS_CAT(launch_fused, CFS_VARIANT)(int nj, FusedParams p, hipStream_t
     case 3096: return launch_fused_inst<3, 96>(p, lds, s);
     case 4096: return launch_fused_inst<4, 96>(p, lds, s);
     case 5096: return launch_fused_inst<5, 96>(p, lds, s);
+    case 6096: return launch_fused_inst<6, 96>(p, lds, s);
+    case 2160: return launch_fused_inst<2, 160>(p, lds, s);
     case 4160: return launch_fused_inst<4, 160>(p, lds, s);
     case 5160: return launch_fused_inst<5, 160>(p, lds, s);
     case 6160: return launch_fused_inst<6, 160>(p, lds, s);
     case 3160: return launch_fused_inst<3, 160>(p, lds, s);
+    case 3256: return launch_fused_inst<3, 256>(p, lds, s);
     case 4256: return launch_fused_inst<4, 256>(p, lds, s);
     case 5256: return launch_fused_inst<5, 256>(p, lds, s);
     case 6256: return launch_fused_inst<6, 256>(p, lds, s);

@@ -219,3 +219,43 @@ def test_single_obstacle_short_horizon_and_ragged_batch(gpu, O):
         assert got.status[b] == want.status and got.iter_O[b] == want.iter_O
         assert np.abs(got.x_[b] - want.x_).max() < TOL_RAD
         np.testing.assert_allclose(got.cost_all[b, :want.iter_O - 1], want.cost_all, rtol=1e-9)
+
+
+@pytest.mark.parametrize("nj,H,mode", [(3, 24, "CFS"), (4, 20, "PSGCFS"), (6, 16, "CFS"), (6, 40, "PSGCFS"), (3, 60, "CFS"), (4, 64, "CFS")])
+def test_other_joint_counts(gpu, O, nj, H, mode):
+    """The kernels are instantiated for 2..6 joints; the drivers only use 5 (and 2).  First nj joints of the M200i
+    (all 6 DH rows exist, robotproperty2.m:24-29), one line obstacle across the sweep."""
+    robot, orobot = gpu.robotproperty2("M200i"), O.robotproperty2("M200i")
+    x0 = np.array([0.7825, 0.0284, 0.2172, 0.1444, -1.1779, 0.3])[:nj]
+    xg = x0 * np.array([-1.0, 1, 1, 1, 1, 1])[:nj]
+    kw = dict(Qp=np.diag([10.0, 10, 1, 1, 1, 1][:nj]), Qv=np.diag([10.0, 10, 1, 1, 1, 1][:nj]), Rblk=np.eye(nj) * 2, cR=50.0, lim=np.ones(nj),
+              max_input_blk=np.ones(nj), epsilon_O=0.1, MAX_O_ITER=12)
+    s = gpu.build_sys_info(robot, nj, H, x0, xg, gpu.line_reference(x0, xg, H), **kw)
+    t = O.build_sys_info(orobot, nj, H, x0, xg, O.line_reference(x0, xg, H), **kw)
+    ob = [gpu.cylinder((3700, 8500, 1), (3700, 8500, 1200), 0.15, 0.2)]
+    noise = np.random.default_rng(nj).standard_normal((12, H * nj)) * 0.1 if mode == "PSGCFS" else None
+    cls = gpu.CFS_FANUC if mode == "CFS" else gpu.PSGCFS_FANUC
+    got = cls(ob, s, "M200i").optimizer(noise=noise)
+    want = O.optimizer("M200i", t, [dict(l=ob[0]["l"], D=0.15, epsilon=0.2)], mode, noise=noise)
+    assert got.status == want.status and got.iter_O == want.iter_O and got.iter_O > 2
+    # PSGCFS never stops early (SURVEY N1): 12 forced iterations amplify the 1e-16 differences of the two arithmetic
+    # paths (7e-7 rad at nj = 6, H = 40), so those cases are held to the north star's bar instead of TOL_RAD
+    assert np.abs(got.x_ - want.x_).max() < (TOL_RAD if mode == "CFS" else 1e-5)
+    np.testing.assert_allclose(got.eval.cost_all, want.cost_all, rtol=1e-8 if mode == "CFS" else 1e-6)
+
+
+def test_two_link_arm_long_horizon(gpu, O):
+    # nj = 2, H = 56: nn = 112 selects the 160-row instantiation for the planar arm (main_2L's own H = 40 uses the 96-row one)
+    robot, orobot = gpu.robotproperty2("2L"), O.robotproperty2("2L")
+    x0, xg, H = np.zeros(2), np.array([np.pi / 2, 0.0]), 56
+    kw = dict(Qp=np.diag([10.0, 1.0]), Qv=np.diag([10.0, 1.0]), Rblk=np.diag([5.0, 4.0]), cR=0.1, lim=np.ones(2), max_input_blk=np.ones(2) * 0.25,
+              epsilon_O=1e-6, MAX_O_ITER=30)
+    x_init = np.tile(np.concatenate([x0, np.zeros(2)]), H)
+    s = gpu.build_sys_info(robot, 2, H, x0, xg, x_init, **kw)
+    t = O.build_sys_info(orobot, 2, H, x0, xg, x_init, **kw)
+    c = np.array([0.3, 0.3, 0.0])
+    ob = [dict(shape="circle", l=np.stack([c, c], axis=1), D=0.05, epsilon=0.05)]
+    got = gpu.CFS_FANUC(ob, s, "2L").optimizer()
+    want = O.optimizer("2L", t, [dict(l=ob[0]["l"], D=0.05, epsilon=0.05)], "CFS")
+    assert got.status == want.status and got.iter_O == want.iter_O
+    assert np.abs(got.x_ - want.x_).max() < 1e-6
