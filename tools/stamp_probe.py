@@ -18,11 +18,13 @@ st = st.astype(np.float64)
 names = ["lin: minima+FD", "qp setup", "step1 scan", "w gather+roll", "d, r=Pd", "z+roll+refine", "steplen/update", "add", "drop", "post (roll,cost)", "lin: sincos+FK", "lin: segment pairs"]
 tot = st.sum(axis=1)
 its = r.iter_O - 1; steps = r.total_iter
-print("clock64 ticks are 100 MHz (s_memtime = constant clock): 1 tick = 10 ns")
+TICK = 1.0 / 21.0   # s_memtime counts shader cycles here (MI355X_MICROARCH.md: tick = shader cycle, ~2.1 GHz), not the 100 MHz the
+                    # formulas below were written for: scale their 10 ns ticks by 1/21
+print("s_memtime ticks = shader cycles (~2.1 GHz); times below are approximate (clock varies with load)")
 for grp, m in (("all", np.ones(B, bool)), ("solved", r.status < 2), ("infeasible", r.status == 2)):
     t = st[m].sum(axis=0)
-    print(f"[{grp}] problems {m.sum()}, outer its {its[m].sum()}, QP steps {steps[m].sum()}, total {t.sum()*1e-2/1e3:.1f} ms of WG time; per step {t[2:9].sum()*10/max(steps[m].sum(),1)/1e3:.2f} us; per-iteration linearise {(t[0]+t[10]+t[11])*10/max((its[m]+ (r.status[m]==2)).sum(),1)/1e3:.2f} us, post {t[9]*10/max(its[m].sum(),1)/1e3:.2f} us")
+    print(f"[{grp}] problems {m.sum()}, outer its {its[m].sum()}, QP steps {steps[m].sum()}, total {t.sum()*1e-2/1e3*TICK:.1f} ms of WG time; per step {t[2:9].sum()*10/max(steps[m].sum(),1)/1e3*TICK:.2f} us; per-iteration linearise {(t[0]+t[10]+t[11])*10/max((its[m]+ (r.status[m]==2)).sum(),1)/1e3*TICK:.2f} us, post {t[9]*10/max(its[m].sum(),1)/1e3*TICK:.2f} us")
     print("   " + ", ".join(f"{n} {100*v/t.sum():.1f}%" for n, v in zip(names, t)))
 worst = np.argsort(-tot)[:5]
-print("slowest problems:", [(int(b), int(r.status[b]), int(r.iter_O[b]), int(steps[b]), round(tot[b]*1e-5, 2)) for b in worst], "(b, status, iter_O, steps, ms)")
-print("sum of WG time / 256 CUs = %.2f ms" % (tot.sum() * 1e-5 / 256))
+print("slowest problems:", [(int(b), int(r.status[b]), int(r.iter_O[b]), int(steps[b]), round(tot[b]*1e-5*TICK, 2)) for b in worst], "(b, status, iter_O, steps, ms)")
+print("sum of WG time / 256 CUs = %.2f ms" % (tot.sum() * 1e-5 * TICK / 256))
