@@ -83,3 +83,15 @@ def test_cubic_resample_end_points(route_wp):
     assert r.shape == (5, 41)
     np.testing.assert_array_equal(r[:, 0], route_wp[:, 0])
     np.testing.assert_allclose(r[:, -1], route_wp[:, -1], atol=1e-15)
+
+
+def test_config5_workload_shapes_and_determinism():
+    from motionplanning_5d_m_amd import workloads
+    s, bt, tri = workloads.config5(B=5, n_tri=3000)
+    s2, bt2, tri2 = workloads.config5(B=5, n_tri=3000)
+    assert s.H == 50 and bt.x_init.shape == (5, 500) and bt.ff.shape == (5, 250) and bt.obs.shape == (5, 1, 6) and bt.noise.shape == (5, 20, 250)
+    assert tri.shape[1:] == (3, 3) and 2000 < tri.shape[0] < 4500
+    assert np.array_equal(tri, tri2) and np.array_equal(bt.x_init, bt2.x_init)
+    base = s.robot.base
+    v = tri.reshape(-1, 3)
+    assert v[:, 0].min() > base[0] + 0.4 and np.isfinite(v).all()      # the map stands in front of the arm, clear of its base
