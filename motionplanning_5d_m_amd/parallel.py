@@ -4,7 +4,7 @@ The reference's only parallel construct is `parfor` over independent RRT seeds f
 gather and a min (Lib/functions/s_Parallel_rrt.m:14-28).  Here the batch dimension is split
 contiguously over the ranks; every rank solves its shard with its own `CFSBatch`; one
 `all_gather` (RCCL over xGMI with backend "nccl", gloo on CPU) returns the converged
-trajectories, inputs, statuses and iteration counts to every rank.
+trajectories, inputs, statuses and iteration counts to every rank, packed into a single collective.
 """
 from __future__ import annotations
 
@@ -21,20 +21,43 @@ def shard_bounds(B: int, rank: int, world: int):
 
 def gather_results(local: dict, B: int, group=None) -> dict:
     """all_gather of per-problem result tensors (leading dim = local shard) into full-batch tensors
-    on every rank.  Shards may be ragged (B not divisible by the world size): tensors are padded to
-    the largest shard for the collective and trimmed afterwards."""
+    on every rank.  Shards may be ragged (B not divisible by the world size): records are padded to
+    the largest shard for the collective and trimmed afterwards.
+
+    All tensors travel in ONE collective: per problem they are packed into a float64 record (int32
+    statuses and counts are exact in fp64), so a step costs one all_gather latency on xGMI instead of one
+    per field (~3.7 KB per problem: u, x_, cost, status, iter_O)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = [shard_bounds(B, r, world)[1] - shard_bounds(B, r, world)[0] for r in range(world)]
-    mx = max(sizes)
-    out = {}
-    for name, t in local.items():
-        assert t.shape[0] == sizes[rank], (name, t.shape, sizes[rank])
-        pad = t if t.shape[0] == mx else torch.cat([t, t.new_zeros((mx - t.shape[0],) + tuple(t.shape[1:]))])
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad.contiguous(), group=group)
-        out[name] = torch.cat([p[: sizes[r]] for r, p in enumerate(parts)])
+    mx, n = max(sizes), sizes[rank]
+    names = list(local)
+    shapes, dtypes, widths = {}, {}, {}
+    cols = []
+    for name in names:
+        t = local[name]
+        assert t.shape[0] == n, (name, t.shape, n)
+        if t.is_floating_point():
+            assert t.dtype == torch.float64, (name, t.dtype)
+        else:
+            assert t.dtype in (torch.int32, torch.int16, torch.uint8, torch.int8, torch.bool), (name, t.dtype)   # exact in fp64
+        shapes[name], dtypes[name] = tuple(t.shape[1:]), t.dtype
+        flat = t.reshape(n, -1).to(torch.float64)
+        widths[name] = flat.shape[1]
+        cols.append(flat)
+    rec = torch.cat(cols, dim=1) if cols else torch.zeros((n, 0), dtype=torch.float64)
+    if n < mx:
+        rec = torch.cat([rec, rec.new_zeros((mx - n, rec.shape[1]))])
+    rec = rec.contiguous()
+    allrec = rec.new_empty((world * mx, rec.shape[1]))
+    dist.all_gather_into_tensor(allrec, rec, group=group)
+    full = torch.cat([allrec[r * mx: r * mx + sizes[r]] for r in range(world)])
+    out, c0 = {}, 0
+    for name in names:
+        w = widths[name]
+        out[name] = full[:, c0:c0 + w].to(dtypes[name]).reshape((full.shape[0],) + shapes[name]).contiguous()
+        c0 += w
     return out
 
 
