@@ -167,13 +167,54 @@ __device__ void seg_tri_update(const double *P0, const double *P1, const double 
     }
 }
 
-// rigorous lower bound of dist(segment, box): the segment is covered by LB_BALLS balls of radius |d| / (2 LB_BALLS),
-// and its own bounding box is at least box-box distance away; a lower bound of a cover is a lower bound of the segment
+// Rigorous lower bound of dist(segment, box), normally the distance itself.  f(t) = dist^2(P0 + t d, box) is convex and
+// piecewise quadratic: on the piece where the set of violated slabs is fixed it is sum_r (e_r + t d_r)^2.  Starting from
+// the middle, minimise the current piece and move there; when the minimiser lies in its own piece it is the global one
+// (convexity).  That takes 2-3 rounds; a point that sits exactly on a slab boundary can make the pattern alternate, and
+// then the bound falls back to a cover of the segment by LB_BALLS balls (radius |d| / (2 LB_BALLS)) plus the box-box
+// distance -- any lower bound of a cover is a lower bound of the segment.
 #ifndef CFS_LB_BALLS
 #define CFS_LB_BALLS 4
 #endif
 __device__ double node_lower_bound(const double *P0, const double *P1, const double *blo, const double *bhi)
 {
+    double d[3];
+    sub3(P1, P0, d);
+    const double len2 = dot3(d, d);
+    if (len2 > 0.0) {
+        double t = 0.5;
+#pragma unroll 1
+        for (int it = 0; it < 5; ++it) {
+            double A = 0.0, B = 0.0, C = 0.0;
+            int pat = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double p = P0[r] + t * d[r];
+                if (p < blo[r]) { const double e = P0[r] - blo[r]; A += d[r] * d[r]; B += e * d[r]; C += e * e; pat |= 1 << (2 * r); }
+                else if (p > bhi[r]) { const double e = P0[r] - bhi[r]; A += d[r] * d[r]; B += e * d[r]; C += e * e; pat |= 2 << (2 * r); }
+            }
+            if (pat == 0) return 0.0;                            // the point is inside the box
+            const double tn = A > 0.0 ? fmin(1.0, fmax(0.0, -B / A)) : t;
+            int pat2 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double p = P0[r] + tn * d[r];
+                if (p < blo[r]) pat2 |= 1 << (2 * r);
+                else if (p > bhi[r]) pat2 |= 2 << (2 * r);
+            }
+            if (pat2 == pat) {                                   // the minimiser of this piece lies in this piece: global minimum
+                double v = 0.0;                                  // sum of squares at tn, term by term: no cancellation when the
+#pragma unroll                                                   // segment touches the box (A tn^2 + 2 B tn + C would lose it)
+                for (int r = 0; r < 3; ++r) {
+                    const double p = P0[r] + tn * d[r];
+                    const double g = fmax(0.0, fmax(blo[r] - p, p - bhi[r]));
+                    v += g * g;
+                }
+                return sqrt(v) * (1.0 - 1e-12) - 1e-13 * (1.0 + sqrt(C));   // shaved: stays a lower bound under rounding
+            }
+            t = tn;
+        }
+    }
     constexpr int NB = CFS_LB_BALLS;
     double bb = 0.0;
 #pragma unroll
@@ -183,9 +224,6 @@ __device__ double node_lower_bound(const double *P0, const double *P1, const dou
         bb += g * g;
     }
     bb = sqrt(bb);
-    double d[3];
-    sub3(P1, P0, d);
-    const double len2 = dot3(d, d);
     if (len2 == 0.0) return bb * (1.0 - 1e-14);              // a point: the box-box bound is the exact point-box distance
     const double rad = sqrt(len2) * (0.5 / NB);
     double sp2 = INFINITY;
