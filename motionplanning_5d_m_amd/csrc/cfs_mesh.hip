@@ -468,9 +468,8 @@ __global__ __launch_bounds__(MESH_THREADS, 2) void mesh_upper_kernel(LinMeshPara
     P.upper_d[(((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm] = mesh_greedy_upper(P.meshes[jm], a6, a6 + 3);
 }
 
-// A link axis is queried in MESH_PIECES equal pieces, each on its own lane: a piece is covered by smaller balls (tighter
-// node bounds, shorter traversals), the pieces far from the surface die at the root against the common bound, and there
-// are MESH_PIECES times more lanes to fill the machine with.  dist(link, T) = min over the pieces of dist(piece, T).
+// A link axis is queried in MESH_PIECES equal pieces: the pieces far from the surface die at the root against the common
+// bound, and the others have short verification sets.  dist(link, T) = min over the pieces of dist(piece, T).
 #ifndef CFS_MESH_PIECES
 #define CFS_MESH_PIECES 4
 #endif
@@ -478,56 +477,226 @@ constexpr int MESH_PIECES = CFS_MESH_PIECES;
 constexpr int PIECE_D = 5;                                   // per piece: raw distance, parameter along the whole axis, closest point on the axis
 constexpr int PIECE_I = 2 + NEAR_CAP;                        // winning triangle, near count (-1: overflow), near triangles
 
+// ---- wave-cooperative query: one wavefront works on ONE query at a time, 64 hierarchy nodes or 64 triangles per round, so no
+// lane waits for another lane's longer traversal.  Same semantics as mesh_query<.., true> (lexicographic minimum, near list).
+#ifndef CFS_CO_QPW
+#define CFS_CO_QPW 16
+#endif
+constexpr int CO_FR = 768, CO_TR = 320, CO_QPW = CFS_CO_QPW;   // frontier / triangle buffer of a wavefront; queries set up per wavefront
+static_assert(64 + 128 * LEAF_TRIS <= CO_TR, "a round of 64 nodes can emit 128 leaves");
+struct CoopLds {
+    int fr[CO_FR];
+    int tr[CO_TR];
+    int ni[NEAR_CAP];
+    float nd[NEAR_CAP];
+};
+__device__ __forceinline__ double wmin64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int prefix_of(unsigned long long mask, int lane) { return __popcll(mask & ((1ull << lane) - 1ull)); }
+
+// false: a buffer would overflow (the caller repeats the query sequentially)
+__device__ bool mesh_query_coop(const DevMesh &m, const double *P0, const double *P1, CoopLds &L, int lane, double bound, double margin,
+                                Best &b, int &near_n, bool &near_over)
+{
+    b.d = bound; b.t = INFINITY; b.tri = -1;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) b.pts[r] = 0.0;
+    near_n = 0; near_over = false;
+    if (m.nt == 0) return true;
+    int nf = 1, nt = 0;
+    if (lane == 0) L.fr[0] = 0;
+    __syncthreads();
+    while (nf > 0 || nt > 0) {
+        if (nf > 0 && nt < 64) {
+            // expand up to 64 inner nodes from the end of the frontier (depth first in blocks of 64)
+            if (nf + 64 > CO_FR) return false;
+            const int take = min(nf, 64);
+            nf -= take;
+            const bool act = lane < take;
+            const int ref = act ? L.fr[nf + lane] : 0;
+            __syncthreads();
+            double lc[2] = {INFINITY, INFINITY};
+            int cr[2] = {0, 0};
+            if (act) {
+                const BvhNode nd = m.nodes[ref];
+                lc[0] = node_lower_bound(P0, P1, nd.lo[0], nd.hi[0]);
+                lc[1] = node_lower_bound(P0, P1, nd.lo[1], nd.hi[1]);
+                cr[0] = nd.child[0]; cr[1] = nd.child[1];
+            }
+            const double lim = b.d + margin;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bool q = act && lc[c] <= lim;
+                const bool inner = q && cr[c] >= 0;
+                const unsigned long long mk = __ballot(inner);
+                if (inner) L.fr[nf + prefix_of(mk, lane)] = cr[c];
+                nf += __popcll(mk);
+                const int code = -(cr[c] + 1), first = code >> 3, cnt = (q && cr[c] < 0) ? (code & 7) : 0;
+#pragma unroll
+                for (int k = 0; k < LEAF_TRIS; ++k) {
+                    const bool has = k < cnt;
+                    const unsigned long long mt = __ballot(has);
+                    if (has) L.tr[nt + prefix_of(mt, lane)] = first + k;
+                    nt += __popcll(mt);
+                }
+            }
+            __syncthreads();
+        } else {
+            // test up to 64 triangles, one per lane
+            const int take = min(nt, 64);
+            nt -= take;
+            const int k = lane < take ? L.tr[nt + lane] : -1;
+            __syncthreads();
+            Best tb;
+            tb.d = INFINITY; tb.t = INFINITY; tb.tri = -1;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tb.pts[r] = 0.0;
+            if (k >= 0) seg_tri_update(P0, P1, m.tri + 9 * (size_t)k, k, tb);
+            const double dmin = wmin64(tb.d);
+            const double tmin = wmin64(tb.d == dmin ? tb.t : INFINITY);
+            if (dmin < b.d || (dmin == b.d && tmin < b.t)) {
+                const unsigned long long win = __ballot(tb.d == dmin && tb.t == tmin);
+                const int wl = (int)__builtin_ctzll(win);
+                b.d = dmin; b.t = tmin; b.tri = __shfl(tb.tri, wl, 64);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) b.pts[r] = __shfl(tb.pts[r], wl, 64);
+            }
+            if (!near_over) {
+                const bool nr = k >= 0 && tb.d <= b.d + margin;
+                const unsigned long long mn = __ballot(nr);
+                const int add = __popcll(mn);
+                if (near_n + add > NEAR_CAP) {                // compact what is there against the current minimum first
+                    const bool keep = lane < near_n && (double)L.nd[lane] <= b.d + margin;
+                    const int ki = lane < near_n ? L.ni[lane] : 0;
+                    const float kd = lane < near_n ? L.nd[lane] : 0.0f;
+                    const unsigned long long mkp = __ballot(keep);
+                    __syncthreads();
+                    if (keep) { L.ni[prefix_of(mkp, lane)] = ki; L.nd[prefix_of(mkp, lane)] = kd; }
+                    near_n = __popcll(mkp);
+                    __syncthreads();
+                }
+                if (near_n + add > NEAR_CAP) near_over = true;
+                else {
+                    if (nr) { L.ni[near_n + prefix_of(mn, lane)] = k; L.nd[near_n + prefix_of(mn, lane)] = __double2float_rd(tb.d); }
+                    near_n += add;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (!near_over) {                                          // final filter against the final minimum
+        const bool keep = lane < near_n && (double)L.nd[lane] <= b.d + margin;
+        const int ki = lane < near_n ? L.ni[lane] : 0;
+        const float kd = lane < near_n ? L.nd[lane] : 0.0f;
+        const unsigned long long mkp = __ballot(keep);
+        __syncthreads();
+        if (keep) { L.ni[prefix_of(mkp, lane)] = ki; L.nd[prefix_of(mkp, lane)] = kd; }
+        near_n = __popcll(mkp);
+        __syncthreads();
+    }
+    return true;
+}
+
 template <int NJ>
-__global__ __launch_bounds__(MESH_THREADS, 2) void mesh_base_kernel(LinMeshParams P)
+__global__ __launch_bounds__(64) void mesh_base_kernel(LinMeshParams P)
 {
     constexpr int NVT = nvt(NJ);
-    __shared__ int s_stack[MESH_STACK * MESH_THREADS];
-    __shared__ float s_lbs[MESH_STACK * MESH_THREADS];
-    __shared__ int s_ni[NEAR_CAP * MESH_THREADS];
-    __shared__ float s_nd[NEAR_CAP * MESH_THREADS];
-    const int e = blockIdx.x * MESH_THREADS + threadIdx.x;
-    if (e >= P.B * P.H * NJ * P.nmesh * MESH_PIECES) return;
-    // piece and link index slowest, waypoint fastest: the lanes of a wavefront hold the same piece of the same link at
-    // neighbouring poses, so their traversals have similar lengths (a wavefront runs as long as its longest lane)
-    const int wp = e % P.H, b = (e / P.H) % P.B, jm = (e / (P.H * P.B)) % P.nmesh, k0 = (e / (P.H * P.B * P.nmesh)) % NJ;
-    const int pc = e / (P.H * P.B * P.nmesh * NJ);
-    if (P.status_done && P.status_done[b] != 0) return;
-    const size_t o = (((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm;
-    double *rec = P.piece_d + (o * MESH_PIECES + pc) * PIECE_D;
-    int *reci = P.piece_i + (o * MESH_PIECES + pc) * PIECE_I;
-    double *recn = P.piece_nd + (o * MESH_PIECES + pc) * NEAR_CAP;
-    double a6[6], d[3];
+    __shared__ CoopLds L;
+    const int lane = threadIdx.x;
+    const int total = P.B * P.H * NJ * P.nmesh * MESH_PIECES;
+    // Stage 1, a query per lane: set it up and test it against the root's two boxes.  Most pieces of most links have nothing
+    // within their bound and end here.  Piece and link index fastest: every wavefront gets its share of the few that survive
+    // (stage 2 takes them one after the other).
+    const int e = blockIdx.x * CO_QPW + lane;
+    bool live = lane < CO_QPW && e < total;
+    int jm = 0, pc = 0;
+    size_t o = 0;
+    bool point = false;
+    double s6[6] = {0, 0, 0, 0, 0, 0}, bound = 0.0;
+    const double margin = 4.0 * P.rb->shift_bound;              // twice what the argument needs (see NearList)
+    if (live) {
+        pc = e % MESH_PIECES;
+        const int k0 = (e / MESH_PIECES) % NJ;
+        jm = (e / (MESH_PIECES * NJ)) % P.nmesh;
+        const int wp = (e / (MESH_PIECES * NJ * P.nmesh)) % P.H, b = e / (MESH_PIECES * NJ * P.nmesh * P.H);
+        live = !(P.status_done && P.status_done[b] != 0);
+        o = (((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm;
+        if (live) {
+            double a6[6], d[3];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) a6[q] = P.ends[(((size_t)b * P.H + wp) * NVT + kvoff(k0 + 1)) * 6 + q];
-    sub3(a6 + 3, a6, d);
-    const bool point = dot3(d, d) == 0.0;                    // M200i links 1 and 3 are points: one "piece"
-    rec[0] = INFINITY; rec[1] = INFINITY; rec[2] = rec[3] = rec[4] = 0.0; reci[0] = -1; reci[1] = 0;
-    if (point && pc > 0) return;
-    double s6[6];
+            for (int q = 0; q < 6; ++q) a6[q] = P.ends[(((size_t)b * P.H + wp) * NVT + kvoff(k0 + 1)) * 6 + q];
+            sub3(a6 + 3, a6, d);
+            point = dot3(d, d) == 0.0;                           // M200i links 1 and 3 are points: one "piece"
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        s6[r] = point || pc == 0 ? a6[r] : a6[r] + ((double)pc / MESH_PIECES) * d[r];
-        s6[3 + r] = point || pc == MESH_PIECES - 1 ? a6[3 + r] : a6[r] + ((double)(pc + 1) / MESH_PIECES) * d[r];
+            for (int r = 0; r < 3; ++r) {
+                s6[r] = point || pc == 0 ? a6[r] : a6[r] + ((double)pc / MESH_PIECES) * d[r];
+                s6[3 + r] = point || pc == MESH_PIECES - 1 ? a6[3 + r] : a6[r] + ((double)(pc + 1) / MESH_PIECES) * d[r];
+            }
+            // Only the minimum over the links and the links within prune_tol of it matter (see mesh_shift_kernel), and the
+            // minimum is at most the smallest greedy upper bound: a piece with nothing closer than `bound` is out.
+            double umin = INFINITY;
+#pragma unroll
+            for (int kk = 0; kk < NJ; ++kk) umin = fmin(umin, P.upper_d[(((size_t)b * P.H + wp) * NJ + kk) * P.nmesh + jm]);
+            bound = (fmax(umin, 0.0001) + P.rb->prune_tol) * (1.0 + 1e-12) + margin;
+            double *rec = P.piece_d + (o * MESH_PIECES + pc) * PIECE_D;
+            int *reci = P.piece_i + (o * MESH_PIECES + pc) * PIECE_I;
+            rec[0] = INFINITY; rec[1] = INFINITY; rec[2] = rec[3] = rec[4] = 0.0; reci[0] = -1; reci[1] = 0;   // "nothing within the bound"
+            bool go = !(point && pc > 0) && P.meshes[jm].nt > 0;
+            if (go) {
+                const BvhNode nd = P.meshes[jm].nodes[0];
+                go = fmin(node_lower_bound(s6, s6 + 3, nd.lo[0], nd.hi[0]), node_lower_bound(s6, s6 + 3, nd.lo[1], nd.hi[1])) <= bound + margin;
+            }
+            live = go;
+        }
     }
-    Best bq;
-    NearList nl;
-    nl.idx = s_ni + threadIdx.x; nl.dd = s_nd + threadIdx.x; nl.n = 0; nl.over = false;
-    nl.margin = 4.0 * P.rb->shift_bound;                    // twice what the argument needs (see NearList)
-    // Only the minimum over the links and the links within prune_tol of it matter (see mesh_shift_kernel), and the minimum
-    // is at most the smallest greedy upper bound: a piece with nothing closer than `bound` is out, usually at the root.
-    double umin = INFINITY;
+    // Stage 2, the survivors one at a time, the whole wavefront on each.
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int src = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        double q6[6];
 #pragma unroll
-    for (int kk = 0; kk < NJ; ++kk) umin = fmin(umin, P.upper_d[(((size_t)b * P.H + wp) * NJ + kk) * P.nmesh + jm]);
-    const double bound = (fmax(umin, 0.0001) + P.rb->prune_tol) * (1.0 + 1e-12) + nl.margin;
-    mesh_query<MESH_THREADS, true>(P.meshes[jm], s6, s6 + 3, -1, s_stack + threadIdx.x, s_lbs + threadIdx.x, bq, &nl, bound);
-    if (bq.tri < 0) return;                                  // nothing within the bound
-    rec[0] = bq.d;
-    rec[1] = point ? 0.0 : ((double)pc + bq.t) / MESH_PIECES;
-    rec[2] = bq.pts[0]; rec[3] = bq.pts[1]; rec[4] = bq.pts[2];
-    reci[0] = bq.tri;
-    reci[1] = nl.over ? -1 : nl.n;
-    for (int i = 0; i < nl.n; ++i) { reci[2 + i] = nl.idx[i * MESH_THREADS]; recn[i] = (double)nl.dd[i * MESH_THREADS]; }
+        for (int r = 0; r < 6; ++r) q6[r] = __shfl(s6[r], src, 64);
+        const double qbound = __shfl(bound, src, 64);
+        const int qjm = __shfl(jm, src, 64), qpc = __shfl(pc, src, 64);
+        const bool qpoint = __shfl((int)point, src, 64) != 0;
+        const unsigned long long qo = __shfl((unsigned long long)o, src, 64);
+        double *rec = P.piece_d + (qo * MESH_PIECES + qpc) * PIECE_D;
+        int *reci = P.piece_i + (qo * MESH_PIECES + qpc) * PIECE_I;
+        double *recn = P.piece_nd + (qo * MESH_PIECES + qpc) * NEAR_CAP;
+        Best bq;
+        int near_n;
+        bool near_over;
+        __syncthreads();
+        if (!mesh_query_coop(P.meshes[qjm], q6, q6 + 3, L, lane, qbound, margin, bq, near_n, near_over)) {
+            // a buffer was about to overflow: lane 0 repeats the query with the sequential traversal (its stack in the same LDS)
+            __syncthreads();
+            NearList nl;
+            nl.idx = L.ni; nl.dd = L.nd; nl.n = 0; nl.over = false; nl.margin = margin;
+            if (lane == 0) mesh_query<1, true>(P.meshes[qjm], q6, q6 + 3, -1, L.fr, reinterpret_cast<float *>(L.tr), bq, &nl, qbound);
+            __syncthreads();
+            bq.d = __shfl(bq.d, 0, 64); bq.t = __shfl(bq.t, 0, 64); bq.tri = __shfl(bq.tri, 0, 64);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) bq.pts[r] = __shfl(bq.pts[r], 0, 64);
+            near_n = __shfl(nl.n, 0, 64);
+            near_over = __shfl((int)nl.over, 0, 64) != 0;
+        }
+        if (bq.tri >= 0) {
+            if (lane == 0) {
+                rec[0] = bq.d;
+                rec[1] = qpoint ? 0.0 : ((double)qpc + bq.t) / MESH_PIECES;
+                rec[2] = bq.pts[0]; rec[3] = bq.pts[1]; rec[4] = bq.pts[2];
+                reci[0] = bq.tri;
+                reci[1] = near_over ? -1 : near_n;
+            }
+            if (!near_over && lane < near_n) { reci[2 + lane] = L.ni[lane]; recn[lane] = (double)L.nd[lane]; }
+        }
+        __syncthreads();
+    }
 }
 
 // pieces -> link: lexicographic minimum (distance, parameter), surrogate, and the union of the pieces' near lists
@@ -741,7 +910,7 @@ static hipError_t launch_linearize_mesh_nj(const LinMeshParams &p, hipStream_t s
     const size_t bh = (size_t)p.B * p.H;
     hipLaunchKernelGGL(mesh_fk_kernel<NJ>, blocks(bh * NE), block, 0, s, p);
     hipLaunchKernelGGL(mesh_upper_kernel<NJ>, blocks(bh * NJ * p.nmesh), block, 0, s, p);
-    hipLaunchKernelGGL(mesh_base_kernel<NJ>, blocks(bh * NJ * p.nmesh * MESH_PIECES), block, 0, s, p);
+    hipLaunchKernelGGL(mesh_base_kernel<NJ>, dim3((unsigned)((bh * NJ * p.nmesh * MESH_PIECES + CO_QPW - 1) / CO_QPW)), dim3(64), 0, s, p);
     hipLaunchKernelGGL(mesh_reduce_kernel<NJ>, blocks(bh * NJ * p.nmesh), block, 0, s, p);
     hipLaunchKernelGGL(mesh_shift_kernel<NJ>, blocks(bh * p.nmesh * (NVT - NJ)), block, 0, s, p);
     hipLaunchKernelGGL(mesh_fd_kernel<NJ>, blocks(bh * p.nmesh), block, 0, s, p);
