@@ -148,3 +148,31 @@ def test_batch_of_seeds_against_one_mesh(gpu, O):
     assert ok.sum() >= 4 and (~ok).sum() >= 2 and np.abs(r.x_[ok] - w.x_[ok]).max() < 1e-6
     slv.set_meshes([])                                             # back to line obstacles only: the mesh slot is a plain (degenerate) obstacle again
     slv.close()
+
+
+def test_tiny_meshes_and_near_tie_overflow(gpu, O):
+    M = gpu.mesh
+    rng = np.random.default_rng(12)
+    # 1-, 2-, 3- and 5-triangle meshes: a single leaf gets an inner root with an empty second child
+    for nt in (1, 2, 3, 5):
+        tri = rng.uniform(-1, 1, (nt, 3, 3))
+        O.mesh_register(7, tri)
+        m = gpu.Mesh(tri=tri)
+        segs = rng.uniform(-2, 2, (130, 6))
+        d, p, t = m.point2surface_dis(segs)
+        od, op, ot = O.mesh_seg_distance(7, segs)
+        assert np.abs(d - od).max() < TOL_DIST and np.array_equal(t, ot)
+        m.close()
+    # A cone whose apex (shared by 24 triangles) is the closest feature for the end of the arm: more than 12 triangles tie within
+    # the shift margin, the near list overflows and the shifted poses of num_jac fall back to seeded traversals.
+    R, s, obs = gpu.main_FANUC_problem()
+    P = O.problem_main_FANUC()
+    apex = np.array([3.606, 8.413, 0.95])
+    a = np.arange(25) * (2 * np.pi / 24)
+    ring = np.stack([apex[0] + 0.12 * np.cos(a), apex[1] + 0.12 * np.sin(a), np.full(25, 0.45)], axis=1)
+    cone = np.stack([np.stack([apex, ring[i], ring[i + 1]]) for i in range(24)])
+    l = O.mesh_register(8, cone)
+    got = gpu.CFS_FANUC([dict(mesh=gpu.Mesh(tri=cone), D=0.2, epsilon=0.25)], s, R).optimizer()
+    want = O.optimizer(P.ROBOT, P.sys_info, [dict(l=l, D=0.2, epsilon=0.25)], "CFS")
+    assert got.status == want.status and got.iter_O == want.iter_O and got.iter_O > 2
+    assert np.abs(got.x_ - want.x_).max() < 1e-6
