@@ -97,7 +97,7 @@ def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, head
     # workgroup per problem; the hardest problem of the batch runs ~4x longer than the average CU load), so
     # `--streams S` keeps S solves in flight, each with its own handle (workspace) and HIP stream: the next
     # solve's workgroups fill the CUs the previous one has already drained.
-    S = max(1, args.streams)
+    S = max(1, args.streams if steps >= 8 else min(args.streams, 4))   # a handful of steps cannot fill 16 queues: 4 measured best at K = 5
     slvs = [pkg.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=B, device=local) for _ in range(S)]
     slv = slvs[0]
     t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()  # noqa: E731
