@@ -33,6 +33,10 @@ namespace {
 #ifndef CFS_ANGLE_ADD
 #define CFS_ANGLE_ADD 0                    // 1: sin/cos of theta +- eps/2 by angle addition (measured: no faster, and the 1e-16 differences it seeds cost parity on the chaotic minority)
 #endif
+#ifndef CFS_REF_A
+#define CFS_REF_A 1e-4                   // refinement of a step direction continues while |r'rho| > A * max(|delta|, tol * n'H^-1 n) ...
+#define CFS_REF_B 1e-9                   // ... or max|rho| > B * max|d|  (rho_a = n_a'z, zero in exact arithmetic)
+#endif
 #ifndef CFS_PR
 #define CFS_PR 64                        // columns of each inverse-Gram row kept in registers
 #endif
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         for (int w = 1; w < 4; ++w)
                             if (red[12 + w] < t1) { t1 = red[12 + w]; l = reinterpret_cast<int *>(red + 16)[w]; }
                         const double ref = fmax(fabs(delta), DEP_TOL_F * spp);
-                        if (pass == 3 || (P.opt & 2) || !(fabs(rr) > 1e-4 * ref || rmax > 1e-9 * (dmax + 1e-300))) break;
+                        if (pass == 3 || (P.opt & 2) || !(fabs(rr) > CFS_REF_A * ref || rmax > CFS_REF_B * (dmax + 1e-300))) break;
                         __syncthreads();                               // red / s_r / s_rho are about to change
                         if (tid < qhi) {                                // dr = P rho ; r += dr
                             const double dr = myact >= 0 ? Pr.dot(s_prow, s_pt, tid, qhi) : 0.0;
