@@ -1,0 +1,51 @@
+"""Developer fuzz: random (robot, joints, horizon, obstacles, solver) shapes, GPU against the oracle.  Prints one line per case."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import motionplanning_5d_m_amd as pkg
+from oracle import oracle as O
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+bad = 0
+for case in range(ncase):
+    rid = rng.choice(["M200i", "M16iB", "2L"], p=[0.5, 0.3, 0.2])
+    nj = 2 if rid == "2L" else int(rng.integers(2, 7))
+    H = int(rng.integers(2, 65))
+    nobs = int(rng.integers(1, 13))
+    mode = str(rng.choice(["CFS", "PSGCFS"]))
+    K = int(rng.integers(1, 9))
+    robot, orobot = pkg.robotproperty2(rid), O.robotproperty2(rid)
+    if rid == "2L":
+        x0, xg = np.zeros(2), np.array([rng.uniform(0.5, 1.5), rng.uniform(-0.3, 0.3)])
+        kw = dict(Qp=np.diag([10.0, 1.0]), Qv=np.diag([10.0, 1.0]), Rblk=np.diag([5.0, 4.0]), cR=0.1, lim=np.ones(2), max_input_blk=np.ones(2) * 0.25)
+        obs = [dict(l=np.stack([c, c], axis=1), D=0.05, epsilon=0.05) for c in (np.array([rng.uniform(0.2, 0.5), rng.uniform(0.2, 0.5), 0.0]) for _ in range(nobs))]
+    else:
+        base = np.array([0.7825, 0.0284, 0.2172, 0.1444, -1.1779, 0.3]) if rid == "M200i" else np.array([0.5, 1.2, 0.1, 0.0, -1.2, 0.2])
+        x0 = (base + rng.uniform(-0.1, 0.1, 6))[:nj]
+        xg = (base * np.array([-1.0, 1, 1, 1, 1, 1]) + rng.uniform(-0.1, 0.1, 6))[:nj]
+        kw = dict(Qp=np.diag([10.0, 10, 1, 1, 1, 1][:nj]), Qv=np.diag([10.0, 10, 1, 1, 1, 1][:nj]), Rblk=np.eye(nj) * 2, cR=50.0, lim=np.ones(nj), max_input_blk=np.ones(nj))
+        c0 = np.array([3150.0, 8500.0]) if rid == "M200i" else np.array([3250.0, 8500.0])
+        obs = []
+        for _ in range(nobs):
+            ang, rad = rng.uniform(0, 2 * np.pi), rng.uniform(500, 1500)
+            x, y = c0 + rad * np.array([np.cos(ang), np.sin(ang)])
+            obs.append(pkg.cylinder((x, y, 1), (x, y, rng.uniform(400, 1500)), 0.1, 0.15))
+    kw.update(epsilon_O=0.05, MAX_O_ITER=K)
+    x_init = pkg.line_reference(x0, xg, H)
+    s = pkg.build_sys_info(robot, nj, H, x0, xg, x_init, **kw)
+    t = O.build_sys_info(orobot, nj, H, x0, xg, O.line_reference(x0, xg, H), **kw)
+    noise = rng.standard_normal((K, H * nj)) * 0.1 if mode == "PSGCFS" else None
+    tag = f"case {case:2d} {rid:6s} nj={nj} H={H:2d} nobs={nobs:2d} {mode:6s} K={K}"
+    try:
+        cls = pkg.CFS_FANUC if mode == "CFS" else pkg.PSGCFS_FANUC
+        got = cls(obs, s, rid).optimizer(noise=noise) if mode == "PSGCFS" else cls(obs, s, rid).optimizer()
+    except pkg.CfsError as e:
+        print(tag, "-> refused:", str(e)[:90]); continue
+    want = O.optimizer(rid, t, [dict(l=o["l"], D=o["D"], epsilon=o["epsilon"]) for o in obs], mode, noise=noise)
+    same = got.status == want.status and got.iter_O == want.iter_O
+    err = np.abs(got.x_ - want.x_).max() if same and got.status < 2 else float("nan")
+    flag = "" if same and not (err > 1e-5) else "   <<<<<<"
+    bad += bool(flag)
+    print(tag, f"-> status {got.status}/{want.status} iter {got.iter_O}/{want.iter_O} steps {got.total_iter}/{want.total_iter} linf {err:.2e}{flag}", flush=True)
+print("flagged", bad, "of", ncase)
