@@ -1,6 +1,6 @@
 """Developer probe: config-3 batch on the GPU vs the oracle batch, plus a first timing."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import motionplanning_5d_m_amd as pkg
 from motionplanning_5d_m_amd import workloads

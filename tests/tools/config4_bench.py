@@ -1,9 +1,9 @@
 """BASELINE config 4 (RRT*-CFS smoothing stage, H=40, 2 obstacles, 4096 routes) on one GPU: one JSON line in bench.py's format.
 The batch is B perturbed copies of the logged RRT route (tests/golden/route_wp_200i_xori.npy = data/200i_xori.mat:route_wp),
 resampled on the device (cfs_build_terms_from_routes_device) and smoothed by CFS_FANUC.
-usage: python tools/config4_bench.py [--batch B] [--steps K] [--warmup W] [--check N]"""
+usage: python tests/tools/config4_bench.py [--batch B] [--steps K] [--warmup W] [--check N]"""
 import argparse, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import motionplanning_5d_m_amd as pkg

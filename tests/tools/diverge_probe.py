@@ -1,6 +1,6 @@
 """Developer probe: first outer iteration at which the device solve and the oracle part ways."""
 import os, sys, copy
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import motionplanning_5d_m_amd as pkg
 from motionplanning_5d_m_amd import workloads

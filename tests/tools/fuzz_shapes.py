@@ -1,6 +1,6 @@
 """Developer fuzz: random (robot, joints, horizon, obstacles, solver) shapes, GPU against the oracle.  Prints one line per case."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import motionplanning_5d_m_amd as pkg
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Developer probe: run each stage of the HIP path against the oracle and print the errors."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import motionplanning_5d_m_amd as pkg
 from oracle import oracle as O

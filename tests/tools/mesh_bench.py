@@ -1,8 +1,8 @@
 """BASELINE config 5 (mesh map, 50 waypoints, 256 seeds) on one GPU: one JSON line in bench.py's format.
 A step = one complete batched solve (mesh linearisation + fused solver, one outer iteration per launch pair).
-usage: python tools/mesh_bench.py [--mode CFS|PSGCFS] [--steps K] [--warmup W] [--check N]"""
+usage: python tests/tools/mesh_bench.py [--mode CFS|PSGCFS] [--steps K] [--warmup W] [--check N]"""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import motionplanning_5d_m_amd as pkg
 from motionplanning_5d_m_amd import workloads
