@@ -29,5 +29,5 @@ rng = np.random.default_rng(1); nz = 0.1 * rng.standard_normal((20, 150))
 compare("FANUC-PSG", R, s, obs, O.problem_main_FANUC(), "PSGCFS", nz)
 R, s, obs = pkg.main_2L_problem(); compare("2L", R, s, obs, O.problem_main_2L())
 R, s, obs = pkg.main_2L_problem(lim=(1, 1)); compare("2L-lim1", R, s, obs, O.problem_main_2L(lim=(1, 1)))
-rw = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "route_wp_200i_xori.npy"))
+rw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden", "route_wp_200i_xori.npy"))
 R, s, obs = pkg.RRTstar_CFS_problem(rw); compare("RRT", R, s, obs, O.problem_RRTstar_CFS(rw))
