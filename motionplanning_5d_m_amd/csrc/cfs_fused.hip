@@ -37,6 +37,9 @@ namespace {
 #define CFS_REF_A 1e-4                   // refinement of a step direction continues while |r'rho| > A * max(|delta|, tol * n'H^-1 n) ...
 #define CFS_REF_B 1e-9                   // ... or max|rho| > B * max|d|  (rho_a = n_a'z, zero in exact arithmetic)
 #endif
+#ifndef CFS_MV_BATCH
+#define CFS_MV_BATCH 16                  // QQ*u: loads in flight per thread
+#endif
 #ifndef CFS_PR
 #define CFS_PR 64                        // columns of each inverse-Gram row kept in registers
 #endif
@@ -838,12 +841,12 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             for (int k = tid; k < HN; k += FT) {
                 double sa[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                 int c = 0;
-                for (; c + 16 <= HN; c += 16) {                 // 16 independent L2 loads in flight per thread
-                    double ld[16];
+                for (; c + CFS_MV_BATCH <= HN; c += CFS_MV_BATCH) {   // independent L2 loads in flight per thread
+                    double ld[CFS_MV_BATCH];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) ld[j] = P.QQ[k + (size_t)(c + j) * nn];
+                    for (int j = 0; j < CFS_MV_BATCH; ++j) ld[j] = P.QQ[k + (size_t)(c + j) * nn];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) sa[j & 7] += ld[j] * s_u[c + j];
+                    for (int j = 0; j < CFS_MV_BATCH; ++j) sa[j & 7] += ld[j] * s_u[c + j];
                 }
                 for (; c < HN; ++c) sa[0] += P.QQ[k + (size_t)c * nn] * s_u[c];
                 const double s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
