@@ -88,10 +88,20 @@ def main():
         dist.destroy_process_group()
 
 
+_WL = {}
+
+
+def _workload(B, rank):
+    """config 3 for this rank, generated once (both solvers are measured on the same batch)"""
+    if (B, rank) not in _WL:
+        _WL[(B, rank)] = workloads.config3(lambda rb, th, ob: pkg.dist_arm(rb, th, ob)[0], B=B, seed=20260101 + rank)
+    return _WL[(B, rank)]
+
+
 def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, headline):
     # ---- synthetic inputs (BASELINE.md section 3), generated with the GPU distance entry point, then resident in HBM
     pkg.lib().cfs_set_device(local)
-    s, bt = workloads.config3(lambda rb, th, ob: pkg.dist_arm(rb, th, ob)[0], B=B, seed=20260101 + rank)
+    s, bt = _workload(B, rank)
     margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
     # Steps are independent solves of the same resident batch.  A single solve ends with a long tail (one
     # workgroup per problem; the hardest problem of the batch runs ~4x longer than the average CU load), so
