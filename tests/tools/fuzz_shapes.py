@@ -7,6 +7,7 @@ from oracle import oracle as O
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+with_mesh = len(sys.argv) > 3 and sys.argv[3] == "mesh"      # append one random mesh obstacle (sphere / box / cylinder) to the arm cases
 bad = 0
 for case in range(ncase):
     rid = rng.choice(["M200i", "M16iB", "2L"], p=[0.5, 0.3, 0.2])
@@ -31,6 +32,18 @@ for case in range(ncase):
             ang, rad = rng.uniform(0, 2 * np.pi), rng.uniform(500, 1500)
             x, y = c0 + rad * np.array([np.cos(ang), np.sin(ang)])
             obs.append(pkg.cylinder((x, y, 1), (x, y, rng.uniform(400, 1500)), 0.1, 0.15))
+    oobs = [dict(l=o["l"], D=o["D"], epsilon=o["epsilon"]) for o in obs]
+    if with_mesh and rid != "2L":
+        from motionplanning_5d_m_amd import mesh as M
+        ang, rad = rng.uniform(0, 2 * np.pi), rng.uniform(0.5, 1.0)
+        c = np.array([c0[0] / 1000 + rad * np.cos(ang), c0[1] / 1000 + rad * np.sin(ang), rng.uniform(0.2, 1.0)])
+        kind = int(rng.integers(0, 3))
+        tri = (M.icosphere(c, rng.uniform(0.05, 0.15), subdiv=int(rng.integers(1, 4))) if kind == 0 else
+               M.box_mesh(c - rng.uniform(0.03, 0.15, 3), c + rng.uniform(0.03, 0.15, 3), n=int(rng.integers(1, 6))) if kind == 1 else
+               M.cylinder_mesh((c[0], c[1]), rng.uniform(0.03, 0.1), 0.0, c[2], nseg=int(rng.integers(6, 30)), nring=int(rng.integers(1, 6))))
+        obs = obs + [dict(mesh=pkg.Mesh(tri=tri), D=0.1, epsilon=0.15)]
+        oobs = oobs + [dict(l=O.mesh_register(case % 16, tri), D=0.1, epsilon=0.15)]
+        nobs += 1
     kw.update(epsilon_O=0.05, MAX_O_ITER=K)
     x_init = pkg.line_reference(x0, xg, H)
     s = pkg.build_sys_info(robot, nj, H, x0, xg, x_init, **kw)
@@ -42,7 +55,7 @@ for case in range(ncase):
         got = cls(obs, s, rid).optimizer(noise=noise) if mode == "PSGCFS" else cls(obs, s, rid).optimizer()
     except pkg.CfsError as e:
         print(tag, "-> refused:", str(e)[:90]); continue
-    want = O.optimizer(rid, t, [dict(l=o["l"], D=o["D"], epsilon=o["epsilon"]) for o in obs], mode, noise=noise)
+    want = O.optimizer(rid, t, oobs, mode, noise=noise)
     same = got.status == want.status and got.iter_O == want.iter_O
     err = np.abs(got.x_ - want.x_).max() if same and got.status < 2 else float("nan")
     flag = "" if same and not (err > 1e-5) else "   <<<<<<"
