@@ -149,13 +149,12 @@ struct cfs_problem {
     double lmax_vel;
     DevRobot hrobot;
     DevBuf<DevRobot> rb;
-    DevBuf<double> QQ, Hinv, Hq, M1, M2, M3, M1n, M2n, lim, maxin, margin;
+    DevBuf<double> QQ, Hinv, Hq, M1n, M2n, lim, maxin, margin;
     DevBuf<double> F1, F2, Cq;   // per-problem cost terms from (x0, xg), set by cfs_set_state_cost
     DevBuf<double> Mr[6];   // rollouts (Bvel*, Bpos*) of the columns of M1n, M2n, Hq
     // workspace (max_batch problems)
-    DevBuf<double> x0, qu, dist, grad, cost_new, cost_old, delta, e_u, Yg, Tg, Pt, u_hist, qu_hist;
-    DevBuf<int> qp_status, qp_iter, noise_row, linkid;
-    DevBuf<unsigned char> done;
+    DevBuf<double> x0, qu, dist, grad, Yg, Pt, u_hist, qu_hist;
+    DevBuf<int> noise_row, linkid;
     // mesh obstacles (cfs_problem_set_meshes): the last nmesh of the nobs obstacles
     int nmesh = 0;
     DevBuf<DevMesh> meshes_d;
@@ -163,18 +162,19 @@ struct cfs_problem {
     DevBuf<int> st_done, m_tri, m_near, m_pi;
     bool prof = false;
     std::vector<hipEvent_t> ev;   // 4 per profiled solve: gemm start/stop, fused start/stop
+    std::vector<hipEvent_t> ev_free;   // recycled events: none is created inside a timed region once the pool is warm
     void release_all()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        ev.clear();
-        rb.release(); QQ.release(); Hinv.release(); Hq.release(); M1.release(); M2.release(); M3.release();
+        for (hipEvent_t e : ev_free) (void)hipEventDestroy(e);
+        ev.clear(); ev_free.clear();
+        rb.release(); QQ.release(); Hinv.release(); Hq.release();
         M1n.release(); M2n.release(); Pt.release(); u_hist.release(); qu_hist.release();
         for (auto &m : Mr) m.release();
         F1.release(); F2.release(); Cq.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
-        grad.release(); cost_new.release(); cost_old.release(); delta.release(); e_u.release();
-        Yg.release(); Tg.release(); qp_status.release(); qp_iter.release(); noise_row.release();
-        linkid.release(); done.release(); meshes_d.release(); st_cost.release(); st_done.release();
+        grad.release(); Yg.release(); noise_row.release();
+        linkid.release(); meshes_d.release(); st_cost.release(); st_done.release();
         m_ends.release(); m_base.release(); m_shift.release(); m_tri.release(); m_near.release(); m_upper.release();
         m_pd.release(); m_pnd.release(); m_pi.release();
     }
@@ -185,6 +185,8 @@ static unsigned long long *g_stamps = nullptr;
 static int g_stamps_B = 0;
 static double *g_dbg = nullptr;
 static int g_dbg_b = -1, g_dbg_cap = 0;
+static const int g_opt = [] { const char *e = getenv("CFS_OPT"); return e ? atoi(e) : 0; }();   // developer A/B switches, read once
+static int g_no_prune = 0;       // cfs_debug_no_prune: linearise without candidate pruning (test of the pruning's bit-exactness)
 
 int cfs_fail(int code, const char *fmt, ...)
 {
@@ -230,6 +232,7 @@ int cfs_debug_stamps(int B, unsigned long long *out)   /* B>0,out==NULL: enable 
     if (hipMalloc(reinterpret_cast<void **>(&g_stamps), (size_t)B * 12 * 8) != hipSuccess) return -1;
     return hipMemset(g_stamps, 0, (size_t)B * 12 * 8) == hipSuccess ? 0 : -1;
 }
+int cfs_debug_no_prune(int on) { g_no_prune = on != 0; return 0; }
 int cfs_debug_trace_read(double *out)   /* out: (cap+1)*8 doubles; out[0] = number of records */
 {
     if (!g_dbg) return -1;
@@ -330,9 +333,8 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
         Hq.assign((size_t)nn * nn, 0.0);
         for (int i = 0; i < nn; ++i) Hq[i + (size_t)i * nn] = 1.0;
     }
-    // family matrices in the gather layout [column (i*,c)][c'][i']
-    std::vector<double> M1((size_t)nn * nn), M2((size_t)nn * nn), M3((size_t)nn * nn);
-    std::vector<double> M1n((size_t)nn * nn), M2n((size_t)nn * nn);   // same columns, natural row order (fused kernel)
+    // family matrices H^{-1}Bpos', H^{-1}Bvel' (columns = constraint position (i, c), natural row order)
+    std::vector<double> M1n((size_t)nn * nn), M2n((size_t)nn * nn);
     {
         std::vector<long double> a1(nn), a2(nn);
         for (int c = 0; c < nj; ++c)
@@ -348,13 +350,6 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
                 }
                 const int col = i * nj + c;
                 for (int r = 0; r < nn; ++r) { M1n[r + (size_t)col * nn] = (double)a1[r]; M2n[r + (size_t)col * nn] = (double)a2[r]; }
-                for (int ip = 0; ip < H; ++ip)
-                    for (int cp = 0; cp < nj; ++cp) {
-                        const size_t o = ((size_t)col * nj + cp) * H + ip;
-                        M1[o] = (double)a1[ip * nj + cp];
-                        M2[o] = (double)a2[ip * nj + cp];
-                        M3[o] = Hq[(ip * nj + cp) + (size_t)col * nn];
-                    }
             }
     }
 
@@ -419,17 +414,16 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     const size_t Bm = (size_t)desc->max_batch;
     hipError_t e = hipSetDevice(p->device);
 #define A_(buf, count) if (e == hipSuccess) e = p->buf.alloc(count)
-    A_(rb, 1); A_(QQ, (size_t)nn * nn); A_(Hinv, (size_t)nn * nn); A_(M1, (size_t)nn * nn); A_(M2, (size_t)nn * nn);
+    A_(rb, 1); A_(QQ, (size_t)nn * nn); A_(Hinv, (size_t)nn * nn);
     for (int m = 0; m < 6; ++m) { A_(Mr[m], (size_t)nn * nn); }
-    A_(M3, (size_t)nn * nn); A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * pt_stride(nn)); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
+    A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * pt_stride(nn)); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
-    A_(cost_new, Bm); A_(cost_old, Bm); A_(delta, Bm); A_(e_u, Bm); A_(Yg, Bm * nn * nn); A_(Tg, Bm * nn * nn);
+    A_(Yg, Bm * nn * nn);
     if (desc->mode == CFS_MODE_CFS) { A_(u_hist, Bm * (size_t)desc->MAX_O_ITER * nn); A_(qu_hist, Bm * (size_t)desc->MAX_O_ITER * nn); }
-    A_(qp_status, Bm); A_(qp_iter, Bm); A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H); A_(done, Bm);
+    A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H);
 #undef A_
 #define U_(buf, src, count) if (e == hipSuccess) e = hipMemcpy(p->buf.p, src, (count) * sizeof(*p->buf.p), hipMemcpyHostToDevice)
     U_(rb, &p->hrobot, 1); U_(QQ, desc->QQ, (size_t)nn * nn); U_(Hinv, Hinv.data(), (size_t)nn * nn);
-    U_(M1, M1.data(), (size_t)nn * nn); U_(M2, M2.data(), (size_t)nn * nn); U_(M3, M3.data(), (size_t)nn * nn);
     U_(M1n, M1n.data(), (size_t)nn * nn); U_(M2n, M2n.data(), (size_t)nn * nn); U_(Hq, Hq.data(), (size_t)nn * nn);
     for (int m = 0; m < 6; ++m) { U_(Mr[m], Mroll[m].data(), (size_t)nn * nn); }
     U_(lim, desc->lim, nj); U_(margin, desc->margin, desc->nobs);
@@ -453,17 +447,19 @@ void cfs_problem_destroy(cfs_problem *p)
     delete p;
 }
 
-static void fill_qp_common(const cfs_problem *p, QpParams &q, int B)
+// family-level fields of the fused kernel's parameter block (everything that does not change across a batch)
+static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
 {
-    memset(&q, 0, sizeof q);
-    q.B = B; q.H = p->d.H; q.nobs = p->d.nobs; q.mode = p->d.mode;
-    q.has_bounds = p->d.mode == CFS_MODE_CFS;
-    q.dt = p->d.robot.delta_t; q.alpha = p->d.alpha;
-    q.M1 = p->M1.p; q.M2 = p->M2.p; q.M3 = p->M3.p;
-    q.lim = p->lim.p; q.maxin = p->maxin.p; q.margin = p->margin.p;
-    q.dist = p->dist.p; q.grad = p->grad.p;
-    q.qp_status = p->qp_status.p; q.qp_iter = p->qp_iter.p;
-    q.Yg = p->Yg.p; q.Tg = p->Tg.p;
+    memset(&fp, 0, sizeof fp);
+    fp.rb = p->rb.p; fp.B = B; fp.H = p->d.H; fp.nobs = p->d.nobs; fp.mode = p->d.mode;
+    fp.has_bounds = p->d.mode == CFS_MODE_CFS; fp.max_o_iter = p->d.MAX_O_ITER;
+    fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O; fp.lmax_vel = p->lmax_vel;
+    fp.M1 = p->M1n.p; fp.M2 = p->M2n.p; fp.M3 = p->Hq.p; fp.QQ = p->QQ.p;
+    fp.M1v = p->Mr[0].p; fp.M1p = p->Mr[1].p; fp.M2v = p->Mr[2].p; fp.M2p = p->Mr[3].p; fp.M3v = p->Mr[4].p; fp.M3p = p->Mr[5].p;
+    fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
+    fp.x0 = p->x0.p;
+    fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(p->nn);
+    fp.opt = g_opt;
 }
 
 int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream)
@@ -480,7 +476,10 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
 
     hipEvent_t e4[4] = {nullptr, nullptr, nullptr, nullptr};
     if (p->prof)
-        for (int k = 0; k < 4; ++k) HIPCHK(hipEventCreate(&e4[k]));
+        for (int k = 0; k < 4; ++k) {
+            if (!p->ev_free.empty()) { e4[k] = p->ev_free.back(); p->ev_free.pop_back(); }
+            else HIPCHK(hipEventCreate(&e4[k]));
+        }
     if (p->prof) HIPCHK(hipEventRecord(e4[0], s));
     if (p->d.mode == CFS_MODE_CFS) {     // unconstrained minimiser -H^{-1} ff (MFMA), constant over the outer loop
         GemvParams g;
@@ -489,22 +488,15 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     }
     if (p->prof) { HIPCHK(hipEventRecord(e4[1], s)); HIPCHK(hipEventRecord(e4[2], s)); }
     FusedParams fp;
-    memset(&fp, 0, sizeof fp);
-    fp.rb = p->rb.p; fp.B = B; fp.H = p->d.H; fp.nobs = p->d.nobs; fp.mode = p->d.mode;
-    fp.has_bounds = p->d.mode == CFS_MODE_CFS; fp.max_o_iter = K; fp.noise_rows = in->noise ? in->noise_rows : 0;
-    fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O; fp.lmax_vel = p->lmax_vel;
-    fp.M1 = p->M1n.p; fp.M2 = p->M2n.p; fp.M3 = p->Hq.p; fp.QQ = p->QQ.p;
-    fp.M1v = p->Mr[0].p; fp.M1p = p->Mr[1].p; fp.M2v = p->Mr[2].p; fp.M2p = p->Mr[3].p; fp.M3v = p->Mr[4].p; fp.M3p = p->Mr[5].p;
-    fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
+    fill_fused_family(p, fp, B);
+    fp.noise_rows = in->noise ? in->noise_rows : 0;
     fp.x_init = in->x_init; fp.xR1 = in->xR1; fp.ff = in->ff; fp.caug = in->caug; fp.obs = in->obs; fp.noise = in->noise;
-    fp.x0 = p->x0.p;
     fp.u = out->u; fp.x_ = out->x_; fp.cost_all = out->cost_all; fp.e_cost_all = out->e_cost_all; fp.e_u_all = out->e_u_all;
     fp.iter_O = out->iter_O; fp.total_iter = out->total_iter; fp.status = out->status;
-    fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(nn);
     fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
     fp.stamps = (g_stamps && B <= g_stamps_B) ? g_stamps : nullptr;
     fp.u_hist = (p->d.mode == CFS_MODE_CFS && K > 0) ? p->u_hist.p : nullptr;
-    { const char *e = getenv("CFS_OPT"); fp.opt = e ? atoi(e) : 0; }
+    fp.no_prune = g_no_prune;
     (void)nx;
     if (p->nmesh == 0) {
         HIPCHK(launch_fused(nj, fp, s));
@@ -752,7 +744,7 @@ int cfs_profile_read(cfs_problem *p, double *solve_kernel_ms, double *gemm_kerne
         HIPCHK(hipEventElapsedTime(&ms, p->ev[4 * k + 2], p->ev[4 * k + 3]));
         fused += ms;
     }
-    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev) p->ev_free.push_back(e);
     p->ev.clear();
     if (solve_kernel_ms) *solve_kernel_ms = fused;
     if (gemm_kernel_ms) *gemm_kernel_ms = gemm;
@@ -798,6 +790,53 @@ static int check_batch(const cfs_problem *p, int B)
     return CFS_SUCCESS;
 }
 
+// The pieces below run the SAME kernel as the whole solve (cfs_solve_fused_kernel, FusedParams::piece), so that the
+// kernel-level parity tests certify the code that is benchmarked.
+
+// stage what the fused kernel's constructor reads; arrays the piece does not use are zero-filled
+struct PieceBuffers {
+    double *x_, *xR1, *ff, *caug, *obs;
+};
+static int stage_piece(cfs_problem *p, Stage &st, int B, const double *x_, const double *xR1, const double *obs, PieceBuffers &pb)
+{
+    const size_t nobs = p->d.nobs;
+    pb.x_ = st.up(x_, (size_t)B * p->nx);
+    pb.xR1 = st.up(xR1, (size_t)B * p->ns);
+    pb.ff = st.up<double>(nullptr, (size_t)B * p->nn);
+    pb.caug = st.up<double>(nullptr, (size_t)B);
+    pb.obs = st.up(obs, (size_t)B * nobs * 6);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    if (!x_) HIPCHK(hipMemset(pb.x_, 0, (size_t)B * p->nx * 8));
+    if (!xR1) HIPCHK(hipMemset(pb.xR1, 0, (size_t)B * p->ns * 8));
+    if (!obs) HIPCHK(hipMemset(pb.obs, 0, (size_t)B * nobs * 6 * 8));
+    HIPCHK(hipMemset(pb.ff, 0, (size_t)B * p->nn * 8));
+    HIPCHK(hipMemset(pb.caug, 0, (size_t)B * 8));
+    return CFS_SUCCESS;
+}
+
+// linearisation of B trajectories into p->dist / p->grad (B x nobs x H [x nj]) and, optionally, linkid
+static int linearize_piece(cfs_problem *p, int B, const PieceBuffers &pb, double *d_dist, double *d_grad, int *d_linkid)
+{
+    const int nj = p->d.njoint;
+    FusedParams fp;
+    fill_fused_family(p, fp, B);
+    fp.x_init = pb.x_; fp.xR1 = pb.xR1; fp.ff = pb.ff; fp.caug = pb.caug; fp.obs = pb.obs;
+    fp.piece = 1; fp.no_prune = g_no_prune;
+    fp.dump_dist = d_dist; fp.dump_grad = d_grad; fp.dump_linkid = d_linkid;
+    if (d_linkid) HIPCHK(hipMemsetAsync(d_linkid, 0, (size_t)B * p->d.nobs * p->d.H * sizeof(int), nullptr));
+    if (p->nmesh > 0) {          // rows of the mesh obstacles come from the hierarchy kernels, as in the whole solve
+        LinMeshParams lm;
+        lm.rb = p->rb.p; lm.B = B; lm.H = p->d.H; lm.nmesh = p->nmesh; lm.meshes = p->meshes_d.p;
+        lm.dist = p->dist.p; lm.grad = p->grad.p;
+        lm.ends = p->m_ends.p; lm.base_d = p->m_base.p; lm.upper_d = p->m_upper.p; lm.base_t = p->m_tri.p; lm.shift_d = p->m_shift.p; lm.near = p->m_near.p; lm.piece_d = p->m_pd.p; lm.piece_i = p->m_pi.p; lm.piece_nd = p->m_pnd.p;
+        lm.x_ = pb.x_; lm.status_done = nullptr;
+        HIPCHK(launch_linearize_mesh(nj, lm, nullptr));
+        fp.nmesh = p->nmesh; fp.ext_dist = p->dist.p; fp.ext_grad = p->grad.p;
+    }
+    HIPCHK(launch_fused(nj, fp, nullptr));
+    return CFS_SUCCESS;
+}
+
 int cfs_linearize(cfs_problem *p, int B, const double *x_, const double *obs, double *dist, int *linkid, double *grad)
 {
     int rc = check_batch(p, B);
@@ -806,18 +845,18 @@ int cfs_linearize(cfs_problem *p, int B, const double *x_, const double *obs, do
     HIPCHK(hipSetDevice(p->device));
     const size_t nobs = p->d.nobs, H = p->d.H, nj = p->d.njoint;
     Stage st;
-    LinParams lp;
-    lp.rb = p->rb.p; lp.B = B; lp.H = p->d.H; lp.nobs = p->d.nobs;
-    lp.x_ = st.up(x_, (size_t)B * p->nx);
-    lp.obs = st.up(obs, (size_t)B * nobs * 6);
-    lp.done = nullptr; lp.dist = p->dist.p; lp.linkid = p->linkid.p; lp.grad = p->grad.p;
+    PieceBuffers pb;
+    rc = stage_piece(p, st, B, x_, nullptr, obs, pb);
+    if (rc) return rc;
+    double *d_dist = st.up<double>(nullptr, (size_t)B * nobs * H);
+    double *d_grad = st.up<double>(nullptr, (size_t)B * nobs * H * nj);
     if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
-    launch_linearize(p->d.njoint, lp, nullptr);
-    HIPCHK(hipGetLastError());
+    rc = linearize_piece(p, B, pb, d_dist, d_grad, p->linkid.p);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(nullptr));
-    st.down(dist, p->dist.p, (size_t)B * nobs * H);
+    st.down(dist, d_dist, (size_t)B * nobs * H);
     st.down(linkid, p->linkid.p, (size_t)B * nobs * H);
-    st.down(grad, p->grad.p, (size_t)B * nobs * H * nj);
+    st.down(grad, d_grad, (size_t)B * nobs * H * nj);
     if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
     return CFS_SUCCESS;
 }
@@ -832,21 +871,22 @@ int cfs_get_con(cfs_problem *p, int B, const double *x_, const double *u, const 
     const size_t nobs = p->d.nobs, H = p->d.H, nj = p->d.njoint, nn = p->nn;
     const size_t rows = nobs * H * (1 + 2 * nj);
     Stage st;
-    LinParams lp;
-    lp.rb = p->rb.p; lp.B = B; lp.H = p->d.H; lp.nobs = p->d.nobs;
-    lp.x_ = st.up(x_, (size_t)B * p->nx);
-    lp.obs = st.up(obs, (size_t)B * nobs * 6);
-    lp.done = nullptr; lp.dist = p->dist.p; lp.linkid = nullptr; lp.grad = p->grad.p;
+    PieceBuffers pb;
+    rc = stage_piece(p, st, B, x_, xR1, obs, pb);
+    if (rc) return rc;
     DenseConParams dc;
     dc.B = B; dc.H = p->d.H; dc.nj = p->d.njoint; dc.nobs = p->d.nobs; dc.dt = p->d.robot.delta_t;
-    dc.dist = p->dist.p; dc.grad = p->grad.p;
+    double *d_dist = st.up<double>(nullptr, (size_t)B * nobs * H);
+    double *d_grad = st.up<double>(nullptr, (size_t)B * nobs * H * nj);
+    dc.dist = d_dist; dc.grad = d_grad;
     dc.u = st.up(u, (size_t)B * nn);
-    dc.xR1 = st.up(xR1, (size_t)B * p->ns);
+    dc.xR1 = pb.xR1;
     dc.lim = p->lim.p; dc.margin = p->margin.p;
     dc.Ainq = st.up<double>(nullptr, (size_t)B * rows * nn);
     dc.binq = st.up<double>(nullptr, (size_t)B * rows);
     if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
-    launch_linearize(p->d.njoint, lp, nullptr);
+    rc = linearize_piece(p, B, pb, d_dist, d_grad, nullptr);
+    if (rc) return rc;
     launch_dense_con(dc, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
@@ -866,34 +906,37 @@ int cfs_qp(cfs_problem *p, int B, const double *lin, const double *u_lin, const 
     const size_t nobs = p->d.nobs, H = p->d.H, nj = p->d.njoint, nn = p->nn;
     const size_t nlam = nobs * H + 4 * nn;
     Stage st;
+    PieceBuffers pb;
+    rc = stage_piece(p, st, B, nullptr, xR1, nullptr, pb);
+    if (rc) return rc;
     double *d_lin = st.up(lin, (size_t)B * nn);
     double *d_u = st.up(u_lin, (size_t)B * nn);
-    QpParams qp;
-    fill_qp_common(p, qp, B);
-    qp.mode = CFS_MODE_CFS;               // prologue: start from x0 (CFS: -H^{-1}ff, PSGCFS: u_ itself)
-    qp.xR1 = st.up(xR1, (size_t)B * p->ns);
-    qp.u = d_u;
-    qp.lambda = lambda ? st.up<double>(nullptr, (size_t)B * nlam) : nullptr;
+    double *d_dist = st.up(dist, (size_t)B * nobs * H);
+    double *d_grad = st.up(grad, (size_t)B * nobs * H * nj);
+    double *d_lam = lambda ? st.up<double>(nullptr, (size_t)B * nlam) : nullptr;
+    int *d_it = st.up<int>(nullptr, (size_t)B), *d_st = st.up<int>(nullptr, (size_t)B);
     if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
-    HIPCHK(hipMemcpy(p->dist.p, dist, (size_t)B * nobs * H * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->grad.p, grad, (size_t)B * nobs * H * nj * sizeof(double), hipMemcpyHostToDevice));
-    if (p->d.mode == CFS_MODE_CFS) {
+    FusedParams fp;
+    fill_fused_family(p, fp, B);
+    fp.x_init = pb.x_; fp.xR1 = pb.xR1; fp.ff = pb.ff; fp.caug = pb.caug; fp.obs = pb.obs;
+    fp.piece = 2;
+    fp.nmesh = p->d.nobs; fp.ext_dist = d_dist; fp.ext_grad = d_grad;     // every row of the linearisation is given
+    fp.u = d_u; fp.total_iter = d_it; fp.status = d_st; fp.dump_lambda = d_lam;
+    fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
+    if (p->d.mode == CFS_MODE_CFS) {      // start point: the unconstrained minimiser -H^{-1} ff (CFS) | u_ itself (projection)
         GemvParams g;
         g.B = B; g.nn = (int)nn; g.M = p->Hinv.p; g.X = d_lin; g.Y = p->x0.p; g.scale = -1.0;
         launch_batched_gemv(g, nullptr);
-        qp.x0 = p->x0.p;
-    } else qp.x0 = d_lin;
-    launch_qp(p->d.njoint, qp, false, nullptr);
-    launch_qp(p->d.njoint, qp, true, nullptr);
+        fp.x0 = p->x0.p;
+    } else fp.x0 = d_lin;
+    HIPCHK(launch_fused(p->d.njoint, fp, nullptr));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     st.down(u, d_u, (size_t)B * nn);
-    if (lambda) st.down(lambda, qp.lambda, (size_t)B * nlam);
-    st.down(qp_iter, p->qp_iter.p, (size_t)B);
-    st.down(status, p->qp_status.p, (size_t)B);
+    if (lambda) st.down(lambda, d_lam, (size_t)B * nlam);
+    st.down(qp_iter, d_it, (size_t)B);
+    st.down(status, d_st, (size_t)B);
     if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
-    if (status)
-        for (int b = 0; b < B; ++b) status[b] = status[b] == QP_OK ? CFS_OK_CONVERGED : (status[b] == QP_INFEASIBLE ? CFS_QP_INFEASIBLE : CFS_NUMERIC);
     return CFS_SUCCESS;
 }
 

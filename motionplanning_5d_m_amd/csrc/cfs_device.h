@@ -27,20 +27,7 @@ struct DevRobot {
 };
 static_assert(sizeof(DevRobot) % 8 == 0, "DevRobot is copied to LDS as doubles");
 
-// ---- K1: linearisation (distance + literal finite-difference Jacobian) -------------------------
-struct LinParams {
-    const DevRobot *rb;          // device copy
-    int B, H, nobs;
-    const double *x_;            // B x (H*2*NJ)
-    const double *obs;           // B x nobs x 6
-    const unsigned char *done;   // B, may be null: problems flagged done are skipped
-    double *dist;                // B x nobs x H
-    int *linkid;                 // B x nobs x H (may be null)
-    double *grad;                // B x nobs x H x NJ
-};
-void launch_linearize(int nj, const LinParams &p, hipStream_t s);
-size_t linearize_lds_bytes(int nj, int nobs);
-
+// ---- plain dist_arm and the dense constraint writer (cfs_geom.hip) ----------------------------
 struct DistArmParams {
     const DevRobot *rb;
     int N, nobs, nj;
@@ -55,7 +42,7 @@ void launch_dist_arm(const DistArmParams &p, hipStream_t s);
 struct DenseConParams {
     int B, H, nj, nobs;
     double dt;
-    const double *dist, *grad;   // as LinParams
+    const double *dist, *grad;   // B x nobs x H, B x nobs x H x nj (the fused kernel's linearisation dump)
     const double *u;             // B x nn
     const double *xR1;           // B x 2nj
     const double *lim, *margin;
@@ -64,44 +51,7 @@ struct DenseConParams {
 };
 void launch_dense_con(const DenseConParams &p, hipStream_t s);
 
-// ---- K2: batched strictly convex QP (dual active set) + rollout --------------------------------
-enum { QP_OK = 0, QP_INFEASIBLE = 2, QP_NUMERIC = 3, QP_OVERFLOW = 4, QP_SKIPPED = 5 };
-
-struct QpParams {
-    int B, H, nobs, mode;        // mode: cfs_mode
-    int has_bounds;              // CFS: 1, PSGCFS: 0
-    double dt, alpha;
-    // problem-family constants
-    const double *M1, *M2, *M3;  // [nn columns][NJ][H]: H^{-1}Bpos', H^{-1}Bvel', H^{-1}
-    const double *lim;           // NJ
-    const double *maxin;         // nn
-    const double *margin;        // nobs
-    // per problem
-    const double *x0;            // CFS: unconstrained minimiser -H^{-1}ff, B x nn (PSGCFS: unused)
-    const double *ff;            // B x nn (PSGCFS gradient step)
-    const double *qu;            // B x nn: QQ*u of the current u (PSGCFS gradient step)
-    const double *noise;         // B x noise_rows x nn or null
-    int noise_rows;
-    const double *xR1;           // B x 2NJ
-    const double *dist, *grad;   // from K1
-    double *u;                   // B x nn: in: linearisation point u_lin, out: new u
-    double *x_;                  // B x H*2NJ: in: old trajectory, out: rolled-out trajectory (may be null)
-    // per problem solver state (may be null for the bare cfs_qp entry point)
-    const unsigned char *done;
-    const int *iter_O;
-    int *noise_row;
-    const double *cost_new, *cost_old_in; // PSGCFS stop_inner test
-    double *cost_old_out;
-    double *delta;               // ||x_new - x_old||
-    double *e_u;                 // ||u_old - u||
-    int *qp_status;              // B
-    int *qp_iter;                // B (steps of this solve)
-    double *lambda;              // optional B x (nobs*H + 4nn)
-    // big-path scratch (global memory), used when the LDS capacity overflows
-    double *Yg;                  // B x nn x nn
-    double *Tg;                  // B x nn x nn
-};
-void launch_qp(int nj, const QpParams &p, bool big, hipStream_t s);
+enum { QP_OK = 0, QP_INFEASIBLE = 2, QP_NUMERIC = 3 };   // outcome of one QP inside the fused kernel
 
 // ---- K3: batched dense products on the matrix cores (fp64 MFMA) --------------------------------
 struct GemvParams {
@@ -112,21 +62,6 @@ struct GemvParams {
     double scale;
 };
 void launch_batched_gemv(const GemvParams &p, hipStream_t s);
-
-struct OuterParams {             // cost + stop test + history after the QP (EVAL.m:51-73)
-    int B, nn, nx, mode, max_o_iter;
-    double epsilon_O;
-    const double *QQ;            // raw sys_info.QQ
-    const double *u, *ff, *caug;
-    double *qu;                  // out: QQ*u
-    const int *qp_status, *qp_iter;
-    const double *delta, *e_u;
-    double *cost_new, *cost_old;
-    int *iter_O, *total_iter, *status;
-    unsigned char *done;
-    double *cost_all, *e_cost_all, *e_u_all;   // B x max_o_iter
-};
-void launch_outer_update(const OuterParams &p, hipStream_t s);
 
 // ---- fused persistent solver: one workgroup owns one problem for its whole outer loop -----------
 struct FusedParams {
@@ -161,6 +96,14 @@ struct FusedParams {
     double *st_qu;               // B x nn      QQ*u
     double *st_cost;             // B x 2       cost_new, cost_old
     int *st_noise, *st_done;     // B           noise rows consumed; 1 when the problem has finished
+    // pieces of the path through the SAME kernel (cfs_linearize / cfs_get_con / cfs_qp, kernel-level parity tests):
+    int piece;                   // 0: whole solve; 1: linearise x_init and return (dump_*); 2: one QP on the given linearisation
+                                 //    (ext_dist / ext_grad with nmesh = nobs, u = linearisation point in, solution out, x0 = start)
+    int no_prune;                // test switch: evaluate every link at every evaluation point of num_jac (no candidate pruning)
+    double *dump_dist;           // B x nobs x H       distances of the first linearisation of this launch (may be null)
+    double *dump_grad;           // B x nobs x H x NJ  Diff of the same
+    int *dump_linkid;            // B x nobs x H       closest link (1-based, line obstacles only)
+    double *dump_lambda;         // B x (nobs*H + 4nn) multipliers of the last QP [collision (j,i) | vel+ | vel- | bound+ | bound-] (may be null)
 };
 // cfs_fused.hip is compiled into three tiers (workgroups per CU / register-resident columns of the inverse Gram matrix):
 //   w1  1 / 64  whole CU per problem: longest on-chip active sets
@@ -195,13 +138,3 @@ struct TermsParams {             // per-problem line reference and cost terms fr
     double *x_init, *xR1, *ff, *caug;
 };
 void launch_build_terms(const TermsParams &p, hipStream_t s);
-
-struct InitParams {
-    int B, nn, nx, mode, max_o_iter;
-    double epsilon_O;
-    const double *x_init, *caug;
-    double *x_, *u, *qu, *cost_new, *cost_old;
-    int *iter_O, *total_iter, *status, *noise_row;
-    unsigned char *done;
-};
-void launch_init(const InitParams &p, hipStream_t s);

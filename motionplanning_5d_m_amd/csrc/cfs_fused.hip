@@ -22,6 +22,7 @@
 //   * rollouts are short prefix sums from LDS, wave reductions use DPP row shifts (no ds_bpermute).
 #include "cfs_geom_dev.h"
 #include <algorithm>
+#include <atomic>
 
 namespace {
 
@@ -51,6 +52,7 @@ namespace {
 #define CFS_CAT(a, b) CFS_CAT2(a, b)
 static_assert(CFS_PR % 8 == 0 && CFS_PR >= 8, "register-resident P columns come in chunks of 8");
 constexpr int FT = 256;                  // threads per workgroup
+constexpr double POLISH_TOL = 1e-13;     // relative drift of an active row that triggers the final projection
 constexpr double DEP_TOL_F = 1e-8;       // dependent if delta <= tol * n'H^{-1}n: above the eps*cond(H) noise floor of Y = H^{-1}N
 enum { CT_COL = 0, CT_VELP = 1, CT_VELM = 2, CT_BNDP = 3, CT_BNDM = 4 };
 __device__ __forceinline__ int mk_code(int type, int i, int jc) { return (type << 16) | (i << 8) | jc; }
@@ -388,12 +390,15 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         iter_O = P.iter_O[b]; total_iter = P.total_iter[b]; status = P.status[b];
         noise_row = P.st_noise[b]; done = P.st_done[b] != 0;
         __syncthreads();
-    } else {
+    } else if (P.piece == 0) {
         double d2 = 0.0;
         for (int e = tid; e < NX; e += FT) { const double v = s_x[e] - 1.0; d2 += v * v; }   // x_old = ones (EVAL.m:47)
         d2 = block_sum(d2, red, tid);
         if (sqrt(d2) < P.epsilon_O) { done = true; status = CFS_OK_CONVERGED; }
         else if (iter_O > P.max_o_iter) { done = true; status = CFS_OK_MAXITER; }
+    } else if (P.piece == 2) {                             // one QP at the caller's linearisation point
+        for (int e = tid; e < HN; e += FT) s_u[e] = P.u[(size_t)b * nn + e];
+        __syncthreads();
     }
 
     PRow<PR, QB> Pr;                                       // row `tid` of P = (N'H^{-1}N)^{-1}
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         // =========================================================================================
         // get_con, distance half (CFS_FANUC.m:110-118): dist -> s_rhs, Diff -> s_g
         // =========================================================================================
-        {
+        if (nseg > 0) {
             const int W = P.lin_w;
             double *s_sc = lds + L.lin;                      // [W][NJ][3][2] sin, cos of theta, theta+eps/2, theta-eps/2 (minus the joint offset)
             double *s_en = s_sc + W * NJ * 6;                // [W][NVT][6]  capsule end points of every link variant
@@ -475,9 +480,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 for (int e = tid; e < Wc * nseg; e += FT) {
                     const int j = e % nseg, wi = e / nseg;
                     double bk[NJ], m0 = INFINITY;
+                    int lk = 0;
 #pragma unroll
-                    for (int k1 = 1; k1 <= NJ; ++k1) { bk[k1 - 1] = s_bd[(wi * NJ + k1 - 1) * nseg + j]; if (bk[k1 - 1] < m0) m0 = bk[k1 - 1]; }
-                    const double thr = fmax(m0, 0.0001) + rb->prune_tol;
+                    for (int k1 = 1; k1 <= NJ; ++k1) { bk[k1 - 1] = s_bd[(wi * NJ + k1 - 1) * nseg + j]; if (bk[k1 - 1] < m0) { m0 = bk[k1 - 1]; lk = k1; } }   // first minimum wins (dist_arm_3D_200i_2.m:25)
+                    if (P.dump_linkid && launched == 0) P.dump_linkid[((size_t)b * nobs + j) * H + w0 + wi] = lk;
+                    const double thr = P.no_prune ? INFINITY : fmax(m0, 0.0001) + rb->prune_tol;
 #pragma unroll
                     for (int k1 = 1; k1 <= NJ; ++k1)
                         if (bk[k1 - 1] < thr) s_list[(k1 - 1) * W * nseg + atomicAdd(&s_cnt[k1 - 1], 1)] = (unsigned short)((wi << 8) | j);
@@ -529,12 +536,20 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             __syncthreads();
         }
 
+        if (P.dump_dist && launched == 0) {                 // the linearisation as cfs_linearize / cfs_get_con return it
+            for (int e = tid; e < nobs * H; e += FT) P.dump_dist[(size_t)b * nobs * H + e] = s_rhs[e];
+            for (int e = tid; e < nobs * HN; e += FT) P.dump_grad[(size_t)b * nobs * HN + e] = s_g[e];
+        }
+        if (P.piece == 1) return;
+
         // =========================================================================================
         // the QP of this outer iteration (CFS_FANUC.m:85 | PSGCFS_FANUC.m:106-128)
         // =========================================================================================
         STAMP(0);                                           // 0: linearisation
         bool skip = false;
-        if (P.mode == CFS_MODE_PSGCFS) {
+        if (P.piece == 2) {                                 // cfs_qp: start point given (CFS: -H^{-1} lin, PSGCFS: u_)
+            for (int k = tid; k < HN; k += FT) xs[k] = P.x0[(size_t)b * nn + k];
+        } else if (P.mode == CFS_MODE_PSGCFS) {
             skip = fabs(cost_new - cost_old) < 1e-4;        // stop_inner, MAX_I_ITER = 1 (PSGCFS_FANUC.m:136-142)
             if (!skip) {
                 cost_old = cost_new;                        // PSGCFS_FANUC.m:89
@@ -552,6 +567,30 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         }
         int qp_status = QP_OK, iters = 0;
         int qhi = 0, nfree = 0;                             // slots in use: [0,qhi) minus the free stack
+        int npolish = 0;
+        // zb = base - sum_a coef[a] * Y[a]   (Y rows [0,QY) in LDS, the rest in global scratch; base == nullptr: zero)
+        auto y_combine = [&](const double *coef, const double *base) {
+            const int qa = min(qhi, QY);
+            for (int k = tid; k < HN; k += FT) {
+                double z0 = base ? base[k] : 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+                int a = 0;
+                for (; a + 4 <= qa; a += 4) {               // four independent chains keep the LDS pipe full
+                    z0 -= coef[a] * s_Y[a * HN + k];
+                    z1 -= coef[a + 1] * s_Y[(a + 1) * HN + k];
+                    z2 -= coef[a + 2] * s_Y[(a + 2) * HN + k];
+                    z3 -= coef[a + 3] * s_Y[(a + 3) * HN + k];
+                }
+                for (; a < qa; ++a) z0 -= coef[a] * s_Y[a * HN + k];
+                for (a = qa; a + 4 <= qhi; a += 4) {
+                    z0 -= coef[a] * Yg[(size_t)a * nn + k];
+                    z1 -= coef[a + 1] * Yg[(size_t)(a + 1) * nn + k];
+                    z2 -= coef[a + 2] * Yg[(size_t)(a + 2) * nn + k];
+                    z3 -= coef[a + 3] * Yg[(size_t)(a + 3) * nn + k];
+                }
+                for (; a < qhi; ++a) z0 -= coef[a] * Yg[(size_t)a * nn + k];
+                zb[k] = (z0 + z1) + (z2 + z3);
+            }
+        };
         if (!skip) {
             // rhs = (d - margin) - Diff'*Bj(1:nj,:)*u   (CFS_FANUC.m:119-120), with Bpos*u from a rollout of u
             for (int k = tid; k < HN; k += FT) wb[k] = s_u[k];
@@ -611,14 +650,38 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 }
                 block_argmin(sbest, cbest, red, tid);
                 STAMP(2);                                   // 2: step 1 (slack scan + argmin)
-                if (cbest == 0x7fffffff) break;              // primal feasible: optimum
+                bool polish = false;
+                if (cbest == 0x7fffffff) {                   // primal feasible: optimum, up to the drift of its active rows
+                    // Every step keeps x - x0 = H^{-1} N lambda exactly, but the refined direction z still leaks ~1e-9 |d| into
+                    // the active normals, and t reaches 1e5..1e8: over ~100 steps of a near-degenerate QP the active rows drift
+                    // off their bounds (problem 939 of config 3: 3e-4 relative in u).  Project back, G c = -s through the
+                    // running inverse: x <- x - Y (P s), lambda <- lambda - P s.  Stationarity is untouched (x moves along Y,
+                    // lambda with it).  The projection runs through the refinement code below (same P row product, same
+                    // combination with Y, same rollout), then the rows are scanned again.
+                    if (qhi == nfree || npolish >= 3) break;
+                    double drift = 0.0;
+                    if (tid < qhi) {
+                        const int ac = s_act[tid];
+                        double sa = 0.0, bb = 0.0;
+                        if (ac >= 0) { sa = slack_of<NJ>(ac, xs, s_g, s_rhs, s_lim, s_v0, s_mx, H, &bb); drift = fabs(sa) / (1.0 + fabs(bb)); }
+                        s_prow[tid] = sa;
+                    }
+                    { double nd = -drift; int dm = 0; block_argmin(nd, dm, red, tid); drift = -nd; }   // block-wide maximum
+                    if (!(drift > POLISH_TOL)) break;
+                    for (int k = tid; k < HN; k += FT) zb[k] = xs[k];
+                    __syncthreads();
+                    polish = true;
+                }
                 const int pc = cbest, ptype = pc >> 16, pi = (pc >> 8) & 0xff, pj = pc & 0xff;
                 const int pidx = ptype == CT_COL ? pj * H + pi : nobs * H + (ptype - 1) * HN + pi * NJ + pj;
                 double sp = sbest, lam_p = 0.0;
 
                 // step 2
                 for (;;) {
-                    if (++iters > maxit) { qp_status = QP_NUMERIC; break; }
+                    if (!polish && ++iters > maxit) { qp_status = QP_NUMERIC; break; }
+                    double spp = 0.0;
+                    const int myact = tid < qhi ? s_act[tid] : -1;
+                    if (!polish) {
                     // w = H^{-1} n_p together with its rollouts (Bvel w, Bpos w): a gather of <= NJ columns of the
                     // family matrices and of their precomputed rollouts -- no prefix sums, one barrier
                     for (int k = tid; k < HN; k += FT) {
@@ -645,42 +708,25 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     __syncthreads();
                     if (P.opt & 1) { roll_lds<NJ>(wb, H, dt, tid); __syncthreads(); }
                     STAMP(3);                               // 3: w gather + rollout
-                    const double spp = ndot<NJ>(pc, wb, s_g, H);
-                    const int myact = tid < qhi ? s_act[tid] : -1;
+                    spp = ndot<NJ>(pc, wb, s_g, H);
                     if (tid < qhi) s_d[tid] = myact >= 0 ? ndot<NJ>(myact, wb, s_g, H) : 0.0;
                     __syncthreads();
                     // r = P d
                     if (tid < qhi) s_r[tid] = myact >= 0 ? Pr.dot(s_d, s_pt, tid, qhi) : 0.0;
                     __syncthreads();
+                    }
                     STAMP(4);                               // 4: d = N'w, r = P d
                     // z = w - Y'r, rollout, then iterative refinement against the true Gram matrix
                     double delta = 0.0, t1 = INFINITY;
                     int l = 0x7fffffff;
+                    bool enter_at_correction = polish;                 // the projection starts at "dr = P rho" with rho = active slacks
                     for (int pass = 0; pass < 4; ++pass) {
-                        const double *coef = pass == 0 ? s_r : s_rho;      // pass>0: correction dr held in s_rho
-                        const int qa = min(qhi, QY);
-                        for (int k = tid; k < HN; k += FT) {
-                            double z0 = pass == 0 ? wb[k] : zb[k], z1 = 0.0, z2 = 0.0, z3 = 0.0;
-                            int a = 0;
-                            for (; a + 4 <= qa; a += 4) {               // four independent chains keep the LDS pipe full
-                                z0 -= coef[a] * s_Y[a * HN + k];
-                                z1 -= coef[a + 1] * s_Y[(a + 1) * HN + k];
-                                z2 -= coef[a + 2] * s_Y[(a + 2) * HN + k];
-                                z3 -= coef[a + 3] * s_Y[(a + 3) * HN + k];
-                            }
-                            for (; a < qa; ++a) z0 -= coef[a] * s_Y[a * HN + k];
-                            for (a = qa; a + 4 <= qhi; a += 4) {
-                                z0 -= coef[a] * Yg[(size_t)a * nn + k];
-                                z1 -= coef[a + 1] * Yg[(size_t)(a + 1) * nn + k];
-                                z2 -= coef[a + 2] * Yg[(size_t)(a + 2) * nn + k];
-                                z3 -= coef[a + 3] * Yg[(size_t)(a + 3) * nn + k];
-                            }
-                            for (; a < qhi; ++a) z0 -= coef[a] * Yg[(size_t)a * nn + k];
-                            zb[k] = (z0 + z1) + (z2 + z3);
-                        }
+                        if (!enter_at_correction) {
+                        y_combine(pass == 0 ? s_r : s_rho, pass == 0 ? wb : zb);       // pass>0: correction dr held in s_rho
                         __syncthreads();
                         roll_lds<NJ>(zb, H, dt, tid);
                         __syncthreads();
+                        if (polish) break;                             // zb = (x, Bvel x, Bpos x) after the projection
                         delta = ndot<NJ>(pc, zb, s_g, H);              // n_p'z
                         if (qhi == nfree) break;                       // empty active set: nothing to refine, t1 = inf
                         // one exchange carries the refinement diagnostics (r'rho, max|rho|, max|d|; rho_a = n_a'z is
@@ -717,12 +763,20 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         const double ref = fmax(fabs(delta), DEP_TOL_F * spp);
                         if (pass == 3 || (P.opt & 2) || !(fabs(rr) > CFS_REF_A * ref || rmax > CFS_REF_B * (dmax + 1e-300))) break;
                         __syncthreads();                               // red / s_r / s_rho are about to change
-                        if (tid < qhi) {                                // dr = P rho ; r += dr
+                        }
+                        enter_at_correction = false;
+                        if (tid < qhi) {                                // dr = P rho ; r += dr   (projection: lambda -= P s)
                             const double dr = myact >= 0 ? Pr.dot(s_prow, s_pt, tid, qhi) : 0.0;
                             s_rho[tid] = dr;
-                            s_r[tid] += dr;
+                            if (polish) s_lam[tid] -= dr; else s_r[tid] += dr;
                         }
                         __syncthreads();
+                    }
+                    if (polish) {
+                        for (int k = tid; k < 3 * HN; k += FT) xs[k] = zb[k];
+                        __syncthreads();
+                        ++npolish;
+                        break;                                         // back to step 1: scan again
                     }
                     STAMP(5);                               // 5: z, rollout, refinement, dual step length
                     const bool dependent = !(delta > DEP_TOL_F * spp);
@@ -739,10 +793,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     }
                     if (!(t < INFINITY)) { qp_status = QP_INFEASIBLE; break; }
                     const bool full = !dependent && t2 <= t1;
-                    if (!dependent) {
-                        for (int k = tid; k < 3 * HN; k += FT) xs[k] += t * zb[k];
-                        fgain += t * delta * (0.5 * t + lam_p);          // Goldfarb-Idnani step (c)(ii)
-                    }
+                    // The primal step is taken even when n_p is classified as dependent (t2 = inf, t = t1): z is then tiny but
+                    // not zero, t1 = lambda_l / r_l can be 1e5..1e8, and x - x0 = H^{-1} N lambda holds only if x moves with
+                    // exactly the r that moves the multipliers.  (Skipping it cost 1e-5 rad on ~1 % of the config-3 batch.)
+                    for (int k = tid; k < 3 * HN; k += FT) xs[k] += t * zb[k];
+                    fgain += t * delta * (0.5 * t + lam_p);              // Goldfarb-Idnani step (c)(ii)
                     if (tid < qhi && myact >= 0) s_lam[tid] -= t * s_r[tid];
                     lam_p += t;
                     STAMP(6);                               // 6: step length, trace, x/lambda update
@@ -798,6 +853,21 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             }
         }
         total_iter += iters;
+        if (P.dump_lambda) {
+            const int nlam = nobs * H + 4 * HN;
+            __syncthreads();
+            for (int e = tid; e < nlam; e += FT) P.dump_lambda[(size_t)b * nlam + e] = 0.0;
+            __syncthreads();
+            if (tid < qhi && s_act[tid] >= 0 && qp_status == QP_OK) {
+                const int ac = s_act[tid], at = ac >> 16, ai = (ac >> 8) & 0xff, aj = ac & 0xff;
+                P.dump_lambda[(size_t)b * nlam + (at == CT_COL ? aj * H + ai : nobs * H + (at - 1) * HN + ai * NJ + aj)] = s_lam[tid];
+            }
+        }
+        if (P.piece == 2) {
+            for (int e = tid; e < HN; e += FT) P.u[(size_t)b * nn + e] = xs[e];
+            if (tid == 0) { P.total_iter[b] = iters; P.status[b] = qp_status == QP_OK ? CFS_OK_CONVERGED : (qp_status == QP_INFEASIBLE ? CFS_QP_INFEASIBLE : CFS_NUMERIC); }
+            return;
+        }
         if (qp_status != QP_OK) {        // the reference would crash here (CFS_FANUC.m:92); report instead
             status = qp_status == QP_INFEASIBLE ? CFS_QP_INFEASIBLE : CFS_NUMERIC;
             done = true;
@@ -884,12 +954,16 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
 template <int NJ, int QB>
 hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
 {
-    static bool attr_set = false;
+    // the function attribute is per device (handles may live on several GPUs of one process: cfs_set_device)
+    static std::atomic<unsigned long long> attr_set{0ull};
     auto kern = cfs_solve_fused_kernel<NJ, QB>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 64 || !((attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev < 64) attr_set.fetch_or(1ull << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(p.B), dim3(FT), lds, s, p);
     return hipGetLastError();

@@ -55,46 +55,6 @@ __device__ __forceinline__ double wsum(double v)
     return v;
 }
 
-// self.eval bookkeeping after Solve_QP / inner_PSG_5: get_cost, store_result, iter_O++, stop_outer
-// (Lib/CFS_FANUC.m:73-77, Lib/EVAL.m:51-73).  One wavefront per problem; qu = QQ*u is already there.
-__global__ __launch_bounds__(CFS_WAVE) void cfs_outer_update_kernel(OuterParams P)
-{
-    const int b = blockIdx.x, lane = threadIdx.x, nn = P.nn;
-    if (P.done[b]) return;
-    const int st = P.qp_status[b];
-    if (st == QP_INFEASIBLE || st == QP_NUMERIC || st == QP_OVERFLOW) {
-        if (lane == 0) {
-            P.status[b] = (st == QP_INFEASIBLE) ? CFS_QP_INFEASIBLE : CFS_NUMERIC;
-            P.total_iter[b] += P.qp_iter[b];
-            P.done[b] = 1;
-        }
-        return;
-    }
-    double quad = 0.0, lin = 0.0;
-    for (int e = lane; e < nn; e += CFS_WAVE) {
-        const double ue = P.u[(size_t)b * nn + e];
-        quad += ue * P.qu[(size_t)b * nn + e];
-        lin += P.ff[(size_t)b * nn + e] * ue;
-    }
-    quad = wsum(quad);
-    lin = wsum(lin);
-    if (lane != 0) return;
-    const double cost = 0.5 * quad + lin + P.caug[b];      // EVAL.m:52
-    const int k = P.iter_O[b] - 1;
-    double cold;
-    if (P.mode == CFS_MODE_CFS) { cold = P.cost_new[b]; P.cost_old[b] = cold; }  // CFS_FANUC.m:67
-    else cold = P.cost_old[b];                             // set inside inner_PSG_5 (PSGCFS_FANUC.m:89)
-    P.cost_all[(size_t)b * P.max_o_iter + k] = cost;       // EVAL.m:56-58
-    P.e_cost_all[(size_t)b * P.max_o_iter + k] = fabs(cold - cost);
-    P.e_u_all[(size_t)b * P.max_o_iter + k] = P.e_u[b];
-    P.cost_new[b] = cost;
-    if (st != QP_SKIPPED) P.total_iter[b] += P.qp_iter[b];
-    const int it = k + 2;
-    P.iter_O[b] = it;                                      // CFS_FANUC.m:77
-    if (P.delta[b] < P.epsilon_O) { P.status[b] = CFS_OK_CONVERGED; P.done[b] = 1; }   // EVAL.m:64-68
-    else if (it > P.max_o_iter) { P.status[b] = CFS_OK_MAXITER; P.done[b] = 1; }       // EVAL.m:69-72
-}
-
 // cost history of a CFS solve from the logged u and QQ*u (EVAL.m:51-59; CFS_FANUC.m:67,73-75): one
 // wavefront per problem; cost_old of iteration k is the cost of iteration k-1, caug (= get_cost(0)) for k = 0.
 __global__ __launch_bounds__(CFS_WAVE) void cfs_cost_history_kernel(CostHistParams P)
@@ -159,46 +119,12 @@ __global__ __launch_bounds__(CFS_WAVE) void cfs_build_terms_kernel(TermsParams P
     }
 }
 
-// constructor state (Lib/CFS_FANUC.m:55-58, Lib/EVAL.m:40-48) and the stop_outer test that precedes
-// the first iteration (CFS_FANUC.m:63-64)
-__global__ __launch_bounds__(CFS_WAVE) void cfs_init_kernel(InitParams P)
-{
-    const int b = blockIdx.x, lane = threadIdx.x;
-    double d2 = 0.0;
-    for (int e = lane; e < P.nx; e += CFS_WAVE) {
-        const double v = P.x_init[(size_t)b * P.nx + e];
-        P.x_[(size_t)b * P.nx + e] = v;
-        d2 += (v - 1.0) * (v - 1.0);                        // x_old = ones (EVAL.m:47)
-    }
-    for (int e = lane; e < P.nn; e += CFS_WAVE) { P.u[(size_t)b * P.nn + e] = 0.0; P.qu[(size_t)b * P.nn + e] = 0.0; }
-    d2 = wsum(d2);
-    if (lane != 0) return;
-    P.cost_new[b] = P.caug[b];                              // get_cost(zeros) (CFS_FANUC.m:63)
-    P.cost_old[b] = 100000.0;                               // EVAL.m:29
-    P.iter_O[b] = 1;
-    P.total_iter[b] = 0;
-    P.noise_row[b] = 0;
-    int done = 0, st = CFS_OK_MAXITER;
-    if (sqrt(d2) < P.epsilon_O) { done = 1; st = CFS_OK_CONVERGED; }
-    else if (1 > P.max_o_iter) { done = 1; st = CFS_OK_MAXITER; }
-    P.status[b] = st;
-    P.done[b] = (unsigned char)done;
-}
-
 }  // namespace
 
 void launch_batched_gemv(const GemvParams &p, hipStream_t s)
 {
     const dim3 grid((p.B + 15) / 16, (p.nn + 16 * GEMV_RT - 1) / (16 * GEMV_RT)), block(CFS_WAVE);
     hipLaunchKernelGGL(cfs_batched_gemv_kernel, grid, block, 0, s, p);
-}
-
-void launch_outer_update(const OuterParams &p, hipStream_t s)
-{
-    GemvParams g;
-    g.B = p.B; g.nn = p.nn; g.M = p.QQ; g.X = p.u; g.Y = p.qu; g.scale = 1.0;
-    launch_batched_gemv(g, s);
-    hipLaunchKernelGGL(cfs_outer_update_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
 }
 
 void launch_cost_history(const CostHistParams &p, hipStream_t s)
@@ -209,9 +135,4 @@ void launch_cost_history(const CostHistParams &p, hipStream_t s)
 void launch_build_terms(const TermsParams &p, hipStream_t s)
 {
     hipLaunchKernelGGL(cfs_build_terms_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
-}
-
-void launch_init(const InitParams &p, hipStream_t s)
-{
-    hipLaunchKernelGGL(cfs_init_kernel, dim3(p.B), dim3(CFS_WAVE), 0, s, p);
 }

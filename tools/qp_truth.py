@@ -1,0 +1,67 @@
+"""Developer tool (CPU): who is right on the first QP of a config-3 problem?  Rebuilds the problem with the oracle's
+distance function, solves the QP with the oracle, then computes the solution on the oracle's active set in extended
+precision (np.longdouble Gaussian elimination of the KKT system) and compares the oracle's and the GPU's u (from
+gpurun_out/iter1_probe.npz) with it."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from types import SimpleNamespace
+from motionplanning_5d_m_amd import workloads
+from oracle import oracle as O
+
+LD = np.longdouble
+def ld_solve(M, r):
+    M = M.astype(LD).copy(); r = r.astype(LD).copy(); n = M.shape[0]
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(M[k:, k])))
+        if p != k: M[[k, p]] = M[[p, k]]; r[[k, p]] = r[[p, k]]
+        f = M[k + 1:, k] / M[k, k]
+        M[k + 1:, k:] -= f[:, None] * M[k, k:][None]
+        r[k + 1:] -= f * r[k]
+    x = np.zeros(n, LD)
+    for k in range(n - 1, -1, -1):
+        x[k] = (r[k] - M[k, k + 1:] @ x[k + 1:]) / M[k, k]
+    return x
+
+def first_qp(s, bt, b, mode):
+    robot = O.robotproperty2("M200i")
+    margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
+    obs = [dict(l=np.stack([bt.obs[b, j, :3], bt.obs[b, j, 3:]], axis=1), epsilon=margin[j], D=margin[j]) for j in range(bt.nobs)]
+    s2 = SimpleNamespace(**vars(s)); s2.xR1 = bt.xR1[b]; s2.robot = robot
+    nn = s.H * 5
+    A, bb, dist, lid, grad = O.get_con("M200i", s2, obs, bt.x_init[b], np.zeros(nn), mode=mode)
+    if mode == "CFS":
+        A = np.vstack([A, np.eye(nn), -np.eye(nn)]); bb = np.concatenate([bb, s.MAX_input, s.MAX_input])
+        G = 0.5 * (s.QQ + s.QQ.T); g0 = bt.ff[b]
+    else:
+        G = np.eye(nn); u_ = -s.alpha * (bt.ff[b] + 10.0 * bt.noise[b, 0] / 2.0); g0 = -u_
+    return G, g0, A, bb
+
+def truth(G, g0, A, bb, act):
+    n, q = G.shape[0], len(act)
+    M = np.zeros((n + q, n + q), LD); M[:n, :n] = G; M[:n, n:] = A[act].T; M[n:, :n] = A[act]
+    r = np.concatenate([-g0, bb[act]]).astype(LD)
+    sol = ld_solve(M, r)
+    return sol[:n], sol[n:]
+
+if __name__ == "__main__":
+    z = np.load("gpurun_out/iter1_probe.npz")
+    robot = O.robotproperty2("M200i")
+    cache = "/tmp/c3_1024.npz"
+    def dist_fn(rb, th, ob):
+        return np.array([[O.dist_arm(robot, t, np.stack([o[:3], o[3:]], axis=1))[0] for o in ob] for t in th])
+    s, bt = workloads.config3(dist_fn, B=1024)
+    mode = sys.argv[1]
+    for b in map(int, sys.argv[2:]):
+        G, g0, A, bb = first_qp(s, bt, b, mode)
+        x, lam, it, st, kkt = O.qp_solve(G, g0, A, bb)
+        act = np.nonzero(lam > 0)[0]
+        xt, lt = truth(G, g0, A, bb, act)
+        sl = bb - A @ xt.astype(float)
+        Na = A[act]
+        W = np.linalg.solve(np.linalg.cholesky(G), Na.T)
+        sv = np.linalg.svd(W, compute_uv=False)
+        gu = z[f"c3_{mode}_1_gu"][b]; wu = z[f"c3_{mode}_1_wu"][b]
+        sc = np.abs(xt).max()
+        print(f"b={b} {mode}: steps {it} st {st} q={len(act)} cond(W)={sv[0]/sv[-1]:.2e} lam max {lam.max():.2e} min_true_lam {float(lt.min()):.2e} min slack(truth) {sl.min():.2e} "
+              f"| rel err: oracle-here {float(np.abs(x - xt).max()/sc):.2e} oracle-box {float(np.abs(wu - xt).max()/sc):.2e} gpu {float(np.abs(gu - xt).max()/sc):.2e}")
