@@ -92,7 +92,7 @@ typedef struct cfs_problem_desc {
     const double *margin;   /* nobs: obs{j}.epsilon (CFS, CFS_FANUC.m:117) / obs{j}.D (PSGCFS_FANUC.m:158) */
     double epsilon_O;       /* sys_info.epsilon_O                                              */
     int MAX_O_ITER;         /* sys_info.MAX_O_ITER                                             */
-    double alpha;           /* sys_info.alpha (PSGCFS step, main_FANUC.m:120)                  */
+    double alpha;           /* sys_info.alpha (PSGCFS step, main_FANUC.m:120); CFS mode does not read it */
     int max_batch;          /* capacity B_max of the handle's device workspace                 */
 } cfs_problem_desc;
 

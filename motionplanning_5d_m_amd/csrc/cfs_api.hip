@@ -107,9 +107,30 @@ struct Stage {
 };
 
 // symmetric positive definite inverse in extended precision (once per problem family)
-bool spd_inverse(int n, const double *Asym, std::vector<double> &inv)
+// lambda_max(G) <= ||G^(2^k)||_inf^(1/2^k) for symmetric G: five squarings are within n^(1/32) of it (+ margin for fp64 rounding)
+double lambda_max_upper(int nn, std::vector<double> G)
 {
-    std::vector<long double> L((size_t)n * n, 0.0L), Li((size_t)n * n, 0.0L);
+    std::vector<double> T2((size_t)nn * nn);
+    double logscale = 0.0;
+    for (int it = 0; it < 5; ++it) {
+        double nrm = 0.0;
+        for (int i = 0; i < nn; ++i) { double s = 0.0; for (int j = 0; j < nn; ++j) s += fabs(G[i + (size_t)j * nn]); if (s > nrm) nrm = s; }
+        if (!(nrm > 0.0)) return 0.0;
+        for (auto &v : G) v /= nrm;
+        logscale = 2.0 * (logscale + log(nrm));
+        for (int i = 0; i < nn; ++i)
+            for (int j = 0; j < nn; ++j) { double s = 0.0; for (int k = 0; k < nn; ++k) s += G[i + (size_t)k * nn] * G[k + (size_t)j * nn]; T2[i + (size_t)j * nn] = s; }
+        G.swap(T2);
+    }
+    double nrm = 0.0;
+    for (int i = 0; i < nn; ++i) { double s = 0.0; for (int j = 0; j < nn; ++j) s += fabs(G[i + (size_t)j * nn]); if (s > nrm) nrm = s; }
+    return exp((logscale + log(nrm)) / 32.0) * 1.001;
+}
+
+bool spd_inverse(int n, const double *Asym, std::vector<double> &inv, std::vector<long double> &Li)
+{
+    std::vector<long double> L((size_t)n * n, 0.0L);
+    Li.assign((size_t)n * n, 0.0L);
     for (int j = 0; j < n; ++j) {
         long double s = Asym[j + (size_t)j * n];
         for (int k = 0; k < j; ++k) s -= L[j + (size_t)k * n] * L[j + (size_t)k * n];
@@ -146,7 +167,7 @@ struct cfs_problem {
     cfs_problem_desc d;
     int device;
     int nn, ns, nx;
-    double lmax_vel;
+    double lmax_vel, lmax_H;
     DevRobot hrobot;
     DevBuf<DevRobot> rb;
     DevBuf<double> QQ, Hinv, Hq, M1n, M2n, lim, maxin, margin;
@@ -321,11 +342,12 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     // H^{-1} of the QP Hessian: QQ symmetrised (quadprog does so silently) for CFS, identity for the
     // PSGCFS projection (PSGCFS_FANUC.m:117)
     std::vector<double> Hinv;
+    std::vector<long double> Li;            // L^{-1} (lower), H = L L'
     {
         std::vector<double> sym((size_t)nn * nn);
         for (int j = 0; j < nn; ++j)
             for (int i = 0; i < nn; ++i) sym[i + (size_t)j * nn] = 0.5 * (desc->QQ[i + (size_t)j * nn] + desc->QQ[j + (size_t)i * nn]);
-        if (!spd_inverse(nn, sym.data(), Hinv)) return fail(CFS_ERR_NOT_SPD, "QQ is not positive definite");
+        if (!spd_inverse(nn, sym.data(), Hinv, Li)) return fail(CFS_ERR_NOT_SPD, "QQ is not positive definite");
     }
     std::vector<double> Hq;   // Hessian inverse used by the QP
     if (desc->mode == CFS_MODE_CFS) Hq = Hinv;
@@ -333,31 +355,52 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
         Hq.assign((size_t)nn * nn, 0.0);
         for (int i = 0; i < nn; ++i) Hq[i + (size_t)i * nn] = 1.0;
     }
-    // family matrices H^{-1}Bpos', H^{-1}Bvel' (columns = constraint position (i, c), natural row order)
-    std::vector<double> M1n((size_t)nn * nn), M2n((size_t)nn * nn);
+    // Family matrices H^{-1}Bpos', H^{-1}Bvel' (columns = constraint position (i, c), natural row order), in extended
+    // precision and rounded ONCE.  The columns of Bpos' / Bvel' (ramps and steps along the horizon) lie in the stiff
+    // subspace of H, so H^{-1}Bpos' is ~cond(H) smaller than the entries of H^{-1} it would be summed from: forming it
+    // from the rounded inverse costs 1e-9..1e-8 relative (measured on config 3: one-step QPs off by 1.4e-8).  It is
+    // therefore computed as L^{-T}(L^{-1}Bpos') from the extended-precision Cholesky factor.
+    std::vector<long double> M1L((size_t)nn * nn), M2L((size_t)nn * nn), HqL((size_t)nn * nn, 0.0L);
     {
-        std::vector<long double> a1(nn), a2(nn);
+        const long double dtl = (long double)dt;
+        std::vector<long double> v1(nn), v2(nn), y1(nn), y2(nn);
         for (int c = 0; c < nj; ++c)
             for (int i = 0; i < H; ++i) {
-                for (int r = 0; r < nn; ++r) {
-                    long double s1 = 0.0L, s2 = 0.0L;
-                    for (int k = 0; k <= i; ++k) {
-                        const long double h = Hq[r + (size_t)(k * nj + c) * nn];
-                        s1 += ((long double)(i - k) + 0.5L) * (long double)dt * (long double)dt * h;
-                        s2 += (long double)dt * h;
-                    }
-                    a1[r] = s1; a2[r] = s2;
-                }
                 const int col = i * nj + c;
-                for (int r = 0; r < nn; ++r) { M1n[r + (size_t)col * nn] = (double)a1[r]; M2n[r + (size_t)col * nn] = (double)a2[r]; }
+                for (int r = 0; r < nn; ++r) { v1[r] = 0.0L; v2[r] = 0.0L; }
+                for (int k = 0; k <= i; ++k) { v1[k * nj + c] = ((long double)(i - k) + 0.5L) * dtl * dtl; v2[k * nj + c] = dtl; }   // Bpos', Bvel' columns
+                if (desc->mode == CFS_MODE_CFS) {
+                    for (int r = 0; r < nn; ++r) {             // y = L^{-1} v
+                        long double s1 = 0.0L, s2 = 0.0L;
+                        for (int k = 0; k <= r; ++k) { s1 += Li[r + (size_t)k * nn] * v1[k]; s2 += Li[r + (size_t)k * nn] * v2[k]; }
+                        y1[r] = s1; y2[r] = s2;
+                    }
+                    for (int r = 0; r < nn; ++r) {             // x = L^{-T} y
+                        long double s1 = 0.0L, s2 = 0.0L;
+                        for (int k = r; k < nn; ++k) { s1 += Li[k + (size_t)r * nn] * y1[k]; s2 += Li[k + (size_t)r * nn] * y2[k]; }
+                        M1L[r + (size_t)col * nn] = s1; M2L[r + (size_t)col * nn] = s2;
+                    }
+                } else
+                    for (int r = 0; r < nn; ++r) { M1L[r + (size_t)col * nn] = v1[r]; M2L[r + (size_t)col * nn] = v2[r]; }
             }
+        if (desc->mode == CFS_MODE_CFS) {
+            for (int i = 0; i < nn; ++i)
+                for (int j = 0; j <= i; ++j) {                 // H^{-1} = Li' Li
+                    long double sacc = 0.0L;
+                    for (int k = i; k < nn; ++k) sacc += Li[k + (size_t)i * nn] * Li[k + (size_t)j * nn];
+                    HqL[i + (size_t)j * nn] = HqL[j + (size_t)i * nn] = sacc;
+                }
+        } else
+            for (int i = 0; i < nn; ++i) HqL[i + (size_t)i * nn] = 1.0L;
     }
+    std::vector<double> M1n((size_t)nn * nn), M2n((size_t)nn * nn);
+    for (size_t e = 0; e < (size_t)nn * nn; ++e) { M1n[e] = (double)M1L[e]; M2n[e] = (double)M2L[e]; }
 
-    // rigorous upper bound of lambda_max(G), G = D'HqD/dt^2 (D = first difference along the waypoints, so that
-    // u = D s/dt for s = Bvel u): lambda_max(G) <= ||G^(2^k)||_inf^(1/2^k); five squarings are within n^(1/32) of it
-    double lmax_vel = 0.0;
+    // rigorous upper bounds of lambda_max(H) and of lambda_max(G), G = D'HD/dt^2 (D = first difference along the waypoints, so
+    // that u = D s/dt for s = Bvel u), H = the QP Hessian (QQ symmetrised | I): the early infeasibility test of the fused kernel
+    double lmax_vel = 0.0, lmax_H = 1.0;
     {
-        std::vector<double> Hs((size_t)nn * nn), G((size_t)nn * nn), T2((size_t)nn * nn);
+        std::vector<double> Hs((size_t)nn * nn), G((size_t)nn * nn);
         for (int j = 0; j < nn; ++j)
             for (int i = 0; i < nn; ++i)
                 Hs[i + (size_t)j * nn] = desc->mode == CFS_MODE_CFS ? 0.5 * ((double)desc->QQ[i + (size_t)j * nn] + desc->QQ[j + (size_t)i * nn]) : (i == j ? 1.0 : 0.0);
@@ -370,24 +413,14 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
         };
         G = Hs; Dt(G, true); Dt(G, false);
         for (auto &v : G) v /= (double)(dt * dt);
-        double logscale = 0.0;
-        for (int it = 0; it < 5; ++it) {
-            double nrm = 0.0;
-            for (int i = 0; i < nn; ++i) { double s = 0.0; for (int j = 0; j < nn; ++j) s += fabs(G[i + (size_t)j * nn]); if (s > nrm) nrm = s; }
-            for (auto &v : G) v /= nrm;
-            logscale = 2.0 * (logscale + log(nrm));
-            for (int i = 0; i < nn; ++i)
-                for (int j = 0; j < nn; ++j) { double s = 0.0; for (int k = 0; k < nn; ++k) s += G[i + (size_t)k * nn] * G[k + (size_t)j * nn]; T2[i + (size_t)j * nn] = s; }
-            G.swap(T2);
-        }
-        double nrm = 0.0;
-        for (int i = 0; i < nn; ++i) { double s = 0.0; for (int j = 0; j < nn; ++j) s += fabs(G[i + (size_t)j * nn]); if (s > nrm) nrm = s; }
-        lmax_vel = exp((logscale + log(nrm)) / 32.0) * 1.001;   // + margin for the fp64 rounding of the squarings
+        lmax_vel = lambda_max_upper(nn, G);
+        if (desc->mode == CFS_MODE_CFS) lmax_H = lambda_max_upper(nn, Hs);   // not 1/alpha: alpha is the caller's PSGCFS step
     }
-    // rollouts of every family column (double integrator: Bvel w = dt*cumsum(w), Bpos w = sum (i-k+1/2) dt^2 w_k)
+    // rollouts of every family column (double integrator: Bvel w = dt*cumsum(w), Bpos w = sum (i-k+1/2) dt^2 w_k),
+    // from the extended-precision columns
     std::vector<double> Mroll[6];
     {
-        const std::vector<double> *src[3] = {&M1n, &M2n, &Hq};
+        const std::vector<long double> *src[3] = {&M1L, &M2L, &HqL};
         for (int m = 0; m < 3; ++m) {
             Mroll[2 * m].assign((size_t)nn * nn, 0.0);
             Mroll[2 * m + 1].assign((size_t)nn * nn, 0.0);
@@ -409,7 +442,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     p->d = *desc;
     p->d.QQ = p->d.Aaug = p->d.Baug = p->d.lim = p->d.MAX_input = p->d.margin = nullptr;
     p->device = g_device;
-    p->nn = nn; p->ns = ns; p->nx = nx; p->lmax_vel = lmax_vel;
+    p->nn = nn; p->ns = ns; p->nx = nx; p->lmax_vel = lmax_vel; p->lmax_H = lmax_H;
     build_dev_robot(desc->robot, p->hrobot);
     const size_t Bm = (size_t)desc->max_batch;
     hipError_t e = hipSetDevice(p->device);
@@ -453,7 +486,7 @@ static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
     memset(&fp, 0, sizeof fp);
     fp.rb = p->rb.p; fp.B = B; fp.H = p->d.H; fp.nobs = p->d.nobs; fp.mode = p->d.mode;
     fp.has_bounds = p->d.mode == CFS_MODE_CFS; fp.max_o_iter = p->d.MAX_O_ITER;
-    fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O; fp.lmax_vel = p->lmax_vel;
+    fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O; fp.lmax_vel = p->lmax_vel; fp.lmax_H = p->lmax_H;
     fp.M1 = p->M1n.p; fp.M2 = p->M2n.p; fp.M3 = p->Hq.p; fp.QQ = p->QQ.p;
     fp.M1v = p->Mr[0].p; fp.M1p = p->Mr[1].p; fp.M2v = p->Mr[2].p; fp.M2p = p->Mr[3].p; fp.M3v = p->Mr[4].p; fp.M3p = p->Mr[5].p;
     fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;

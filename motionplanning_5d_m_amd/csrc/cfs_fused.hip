@@ -630,7 +630,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     p3 += xs[HN + k] * xs[HN + k];
                 }
                 block_sum4(p0, p1, p2, p3, red, tid);
-                const double lmax = P.mode == CFS_MODE_CFS ? 1.0 / P.alpha : 1.0;
+                const double lmax = P.lmax_H;
                 const double ru = sqrt(p0) + sqrt(p1), rs = sqrt(p2) + sqrt(p3);
                 fbound = 1.0001 * 0.5 * fmin(lmax * ru * ru, P.lmax_vel * rs * rs);
             }

@@ -112,6 +112,21 @@ def test_cfs_with_a_mesh_obstacle(gpu, O, with_line):
     assert d_line.min() < 0.25 - 1e-2 and d_new.min() > 0.25 - 1e-5
 
 
+def test_get_con_with_a_mesh_obstacle(gpu, O):
+    # the public self.Ainq / self.binq of a handle with mesh obstacles: the mesh rows come from the hierarchy kernels,
+    # not from a degenerate segment at the origin (CFS_FANUC.m:101-135 with dist_arm_surf_200i as the distance function)
+    R, s, g_obs, P, o_obs, _ = _mesh_problem(gpu, O, "CFS", True)
+    slv = gpu.CFS_FANUC(g_obs, s, R)
+    slv.get_con()
+    A, b, dist, lid, grad = O.get_con(P.ROBOT, P.sys_info, o_obs, P.sys_info.x_, np.zeros(s.H * s.nu))
+    assert slv.Ainq.shape == A.shape
+    np.testing.assert_allclose(slv.binq, b, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(slv.Ainq, A, rtol=0, atol=5e-8)      # finite differences over facets: eps = 1e-5 amplifies 1e-13
+    d_g, _, g_g = slv._batch.linearize(np.asarray(s.x_)[None], gpu.obs_to_array(g_obs)[None])
+    np.testing.assert_allclose(d_g[0], dist, rtol=0, atol=1e-12)
+    assert np.abs(d_g[0][-1]).max() > 0.05                          # the mesh rows are real distances
+
+
 def test_psgcfs_with_a_mesh_obstacle(gpu, O):
     # 20 forced iterations over a faceted surface: the finite-difference Jacobian (eps = 1e-5) jumps where the closest
     # facet changes, and the ORACLE ITSELF moves by 1e-4 rad when its x_init is perturbed by 1e-12 on the 488-triangle

@@ -170,6 +170,28 @@ def test_m16ib_model_and_three_obstacles(gpu, O):
     assert got.status == want.status and got.iter_O == want.iter_O and np.abs(got.x_ - want.x_).max() < TOL_RAD
 
 
+def test_cfs_mode_does_not_depend_on_alpha(gpu):
+    """sys_info.alpha is PSGCFS's step (main_FANUC.m:120).  The CFS kernel's early infeasibility bound needs
+    lambda_max(QQ); it is bounded rigorously at cfs_problem_create, not read from 1/alpha -- a CFS handle created with
+    alpha = 0 or 1.0 must give bit-identical results, infeasibility verdicts included."""
+    from motionplanning_5d_m_amd import workloads
+    s, bt = workloads.config3(lambda rb, th, ob: gpu.dist_arm(rb, th, ob)[0], B=96)
+    ref = None
+    for alpha in (s.alpha, 0.0, 1.0):
+        s2 = copy.copy(s)
+        s2.alpha = alpha
+        slv = gpu.CFSBatch(s2, bt.nobs, bt.margin_cfs, mode="CFS", max_batch=96)
+        got = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs)
+        slv.close()
+        if ref is None:
+            ref = got
+            assert (got.status == 2).sum() >= 10 and (got.status == 0).sum() >= 30
+        else:
+            np.testing.assert_array_equal(got.status, ref.status)
+            np.testing.assert_array_equal(got.x_, ref.x_)
+            np.testing.assert_array_equal(got.total_iter, ref.total_iter)
+
+
 def test_zero_iterations_and_max_iter_edge(gpu):
     R, s, obs = gpu.main_FANUC_problem()
     s0 = copy.copy(s); s0.MAX_O_ITER = 0
