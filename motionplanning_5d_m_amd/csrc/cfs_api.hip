@@ -207,6 +207,7 @@ static int g_stamps_B = 0;
 static double *g_dbg = nullptr;
 static int g_dbg_b = -1, g_dbg_cap = 0;
 static const int g_opt = [] { const char *e = getenv("CFS_OPT"); return e ? atoi(e) : 0; }();   // developer A/B switches, read once
+static const double g_polish_tol = [] { const char *e = getenv("CFS_POLISH_TOL"); return e ? atof(e) : 1e-11; }();   // = the scan's feasibility tolerance
 static int g_no_prune = 0;       // cfs_debug_no_prune: linearise without candidate pruning (test of the pruning's bit-exactness)
 
 int cfs_fail(int code, const char *fmt, ...)
@@ -355,46 +356,30 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
         Hq.assign((size_t)nn * nn, 0.0);
         for (int i = 0; i < nn; ++i) Hq[i + (size_t)i * nn] = 1.0;
     }
-    // Family matrices H^{-1}Bpos', H^{-1}Bvel' (columns = constraint position (i, c), natural row order), in extended
-    // precision and rounded ONCE.  The columns of Bpos' / Bvel' (ramps and steps along the horizon) lie in the stiff
-    // subspace of H, so H^{-1}Bpos' is ~cond(H) smaller than the entries of H^{-1} it would be summed from: forming it
-    // from the rounded inverse costs 1e-9..1e-8 relative (measured on config 3: one-step QPs off by 1.4e-8).  It is
-    // therefore computed as L^{-T}(L^{-1}Bpos') from the extended-precision Cholesky factor.
-    std::vector<long double> M1L((size_t)nn * nn), M2L((size_t)nn * nn), HqL((size_t)nn * nn, 0.0L);
+    // Family matrices H^{-1}Bpos', H^{-1}Bvel' (columns = constraint position (i, c), natural row order): extended-precision
+    // sums over the entries of the ONE rounded matrix Hq, on purpose.  Every product n_a'H^{-1}n_p the kernel forms is then
+    // exactly symmetric in (a, p) -- the QP is solved for a Hessian inverse that differs from the true one by 1 ulp per entry,
+    // which is harmless -- whereas columns taken from a more accurate solve L^{-T}(L^{-1}Bpos') disagree with the rounded Hq
+    // columns of the bound rows by eps*cond(H) ~ 1e-10: the step refinement then never reaches its residual target and runs
+    // all its passes (measured: CFS mode 30 % slower, same answers).
+    std::vector<double> M1n((size_t)nn * nn), M2n((size_t)nn * nn);
     {
-        const long double dtl = (long double)dt;
-        std::vector<long double> v1(nn), v2(nn), y1(nn), y2(nn);
+        std::vector<long double> a1(nn), a2(nn);
         for (int c = 0; c < nj; ++c)
             for (int i = 0; i < H; ++i) {
-                const int col = i * nj + c;
-                for (int r = 0; r < nn; ++r) { v1[r] = 0.0L; v2[r] = 0.0L; }
-                for (int k = 0; k <= i; ++k) { v1[k * nj + c] = ((long double)(i - k) + 0.5L) * dtl * dtl; v2[k * nj + c] = dtl; }   // Bpos', Bvel' columns
-                if (desc->mode == CFS_MODE_CFS) {
-                    for (int r = 0; r < nn; ++r) {             // y = L^{-1} v
-                        long double s1 = 0.0L, s2 = 0.0L;
-                        for (int k = 0; k <= r; ++k) { s1 += Li[r + (size_t)k * nn] * v1[k]; s2 += Li[r + (size_t)k * nn] * v2[k]; }
-                        y1[r] = s1; y2[r] = s2;
+                for (int r = 0; r < nn; ++r) {
+                    long double s1 = 0.0L, s2 = 0.0L;
+                    for (int k = 0; k <= i; ++k) {
+                        const long double h = Hq[r + (size_t)(k * nj + c) * nn];
+                        s1 += ((long double)(i - k) + 0.5L) * (long double)dt * (long double)dt * h;
+                        s2 += (long double)dt * h;
                     }
-                    for (int r = 0; r < nn; ++r) {             // x = L^{-T} y
-                        long double s1 = 0.0L, s2 = 0.0L;
-                        for (int k = r; k < nn; ++k) { s1 += Li[k + (size_t)r * nn] * y1[k]; s2 += Li[k + (size_t)r * nn] * y2[k]; }
-                        M1L[r + (size_t)col * nn] = s1; M2L[r + (size_t)col * nn] = s2;
-                    }
-                } else
-                    for (int r = 0; r < nn; ++r) { M1L[r + (size_t)col * nn] = v1[r]; M2L[r + (size_t)col * nn] = v2[r]; }
-            }
-        if (desc->mode == CFS_MODE_CFS) {
-            for (int i = 0; i < nn; ++i)
-                for (int j = 0; j <= i; ++j) {                 // H^{-1} = Li' Li
-                    long double sacc = 0.0L;
-                    for (int k = i; k < nn; ++k) sacc += Li[k + (size_t)i * nn] * Li[k + (size_t)j * nn];
-                    HqL[i + (size_t)j * nn] = HqL[j + (size_t)i * nn] = sacc;
+                    a1[r] = s1; a2[r] = s2;
                 }
-        } else
-            for (int i = 0; i < nn; ++i) HqL[i + (size_t)i * nn] = 1.0L;
+                const int col = i * nj + c;
+                for (int r = 0; r < nn; ++r) { M1n[r + (size_t)col * nn] = (double)a1[r]; M2n[r + (size_t)col * nn] = (double)a2[r]; }
+            }
     }
-    std::vector<double> M1n((size_t)nn * nn), M2n((size_t)nn * nn);
-    for (size_t e = 0; e < (size_t)nn * nn; ++e) { M1n[e] = (double)M1L[e]; M2n[e] = (double)M2L[e]; }
 
     // rigorous upper bounds of lambda_max(H) and of lambda_max(G), G = D'HD/dt^2 (D = first difference along the waypoints, so
     // that u = D s/dt for s = Bvel u), H = the QP Hessian (QQ symmetrised | I): the early infeasibility test of the fused kernel
@@ -416,11 +401,10 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
         lmax_vel = lambda_max_upper(nn, G);
         if (desc->mode == CFS_MODE_CFS) lmax_H = lambda_max_upper(nn, Hs);   // not 1/alpha: alpha is the caller's PSGCFS step
     }
-    // rollouts of every family column (double integrator: Bvel w = dt*cumsum(w), Bpos w = sum (i-k+1/2) dt^2 w_k),
-    // from the extended-precision columns
+    // rollouts of every family column (double integrator: Bvel w = dt*cumsum(w), Bpos w = sum (i-k+1/2) dt^2 w_k)
     std::vector<double> Mroll[6];
     {
-        const std::vector<long double> *src[3] = {&M1L, &M2L, &HqL};
+        const std::vector<double> *src[3] = {&M1n, &M2n, &Hq};
         for (int m = 0; m < 3; ++m) {
             Mroll[2 * m].assign((size_t)nn * nn, 0.0);
             Mroll[2 * m + 1].assign((size_t)nn * nn, 0.0);
@@ -493,6 +477,7 @@ static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
     fp.x0 = p->x0.p;
     fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(p->nn);
     fp.opt = g_opt;
+    fp.polish_tol = g_polish_tol;
 }
 
 int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream)

@@ -70,6 +70,7 @@ struct FusedParams {
     int qy, lin_w;               // filled by launch_fused: Y rows held in LDS, waypoints per linearisation tile
     double dt, alpha, epsilon_O;
     double lmax_vel;             // rigorous upper bound of lambda_max(D'HD/dt^2): curvature of the QP objective in velocity space
+    double polish_tol;           // relative drift |slack| / (1 + |bound|) of an active row at the optimum that triggers the projection
     double lmax_H;               // rigorous upper bound of lambda_max(H), H = QQ symmetrised (CFS) | I (PSGCFS projection)
     const double *M1, *M2, *M3;  // nn x nn column-major: H^{-1}Bpos', H^{-1}Bvel', H^{-1} (natural row order)
     const double *M1v, *M1p, *M2v, *M2p, *M3v, *M3p;   // Bvel* and Bpos* of every column of M1, M2, M3

@@ -52,7 +52,6 @@ namespace {
 #define CFS_CAT(a, b) CFS_CAT2(a, b)
 static_assert(CFS_PR % 8 == 0 && CFS_PR >= 8, "register-resident P columns come in chunks of 8");
 constexpr int FT = 256;                  // threads per workgroup
-constexpr double POLISH_TOL = 1e-13;     // relative drift of an active row that triggers the final projection
 constexpr double DEP_TOL_F = 1e-8;       // dependent if delta <= tol * n'H^{-1}n: above the eps*cond(H) noise floor of Y = H^{-1}N
 enum { CT_COL = 0, CT_VELP = 1, CT_VELM = 2, CT_BNDP = 3, CT_BNDM = 4 };
 __device__ __forceinline__ int mk_code(int type, int i, int jc) { return (type << 16) | (i << 8) | jc; }
@@ -667,7 +666,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         s_prow[tid] = sa;
                     }
                     { double nd = -drift; int dm = 0; block_argmin(nd, dm, red, tid); drift = -nd; }   // block-wide maximum
-                    if (!(drift > POLISH_TOL)) break;
+                    if (!(drift > P.polish_tol)) break;
                     for (int k = tid; k < HN; k += FT) zb[k] = xs[k];
                     __syncthreads();
                     polish = true;

@@ -28,3 +28,4 @@ for grp, m in (("all", np.ones(B, bool)), ("solved", r.status < 2), ("infeasible
 worst = np.argsort(-tot)[:5]
 print("slowest problems:", [(int(b), int(r.status[b]), int(r.iter_O[b]), int(steps[b]), round(tot[b]*1e-5*TICK, 2)) for b in worst], "(b, status, iter_O, steps, ms)")
 print("sum of WG time / 256 CUs = %.2f ms" % (tot.sum() * 1e-5 * TICK / 256))
+np.savez(f"gpurun_out/stamps_{mode}.npz", st=st, status=r.status, iter_O=r.iter_O, steps=r.total_iter)
