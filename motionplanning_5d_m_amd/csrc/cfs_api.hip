@@ -227,9 +227,11 @@ void cfs_build_dev_robot(const cfs_robot &r, DevRobot &d) { build_dev_robot(r, d
 bool fused_fits(int nj, int H, int nobs) { return fused_fits_w1(nj, H, nobs); }
 hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
 {
+    // w2s is compiled for the identity Hessian only (PSGCFS), w2m for QQ only (CFS), w1 for both
     static const char *force = getenv("CFS_TIER");
-    int tier = p.mode == CFS_MODE_PSGCFS ? 2 : 1;
-    if (force) tier = !strcmp(force, "w1") ? 0 : (!strcmp(force, "w2m") ? 1 : (!strcmp(force, "w2s") ? 2 : tier));
+    const bool ident = p.mode == CFS_MODE_PSGCFS;
+    int tier = ident ? 2 : 1;
+    if (force && !strcmp(force, "w1")) tier = 0;
     if (tier == 2 && fused_fits_w2s(nj, p.H, p.nobs)) return launch_fused_w2s(nj, p, s);
     if (tier == 1 && fused_fits_w2m(nj, p.H, p.nobs)) return launch_fused_w2m(nj, p, s);
     return launch_fused_w1(nj, p, s);

@@ -147,6 +147,17 @@ __device__ __forceinline__ double wave_scan_incl(double v)
     return v;
 }
 
+// the same over each half of the wavefront separately (lanes 0-31 and 32-63): two joints per wavefront when H <= 32
+__device__ __forceinline__ double half_scan_incl(double v)
+{
+    v += dpp_f64<0x111, 0xf>(0.0, v);   // row_shr:1
+    v += dpp_f64<0x112, 0xf>(0.0, v);   // row_shr:2
+    v += dpp_f64<0x114, 0xf>(0.0, v);   // row_shr:4
+    v += dpp_f64<0x118, 0xf>(0.0, v);   // row_shr:8
+    v += dpp_f64<0x142, 0xa>(0.0, v);   // row_bcast:15 -> rows 1,3
+    return v;
+}
+
 // (Bvel v, Bpos v) of the vector in buf[0..HN) -> buf[HN..2HN), buf[2HN..3HN).  Lane i of a wavefront
 // owns waypoint i (H <= 64); the workgroup's wavefronts share the joints.  Two DPP prefix sums per joint:
 // Bvel v = dt*cumsum(v), Bpos v = dt*cumsum(Bvel v) - dt/2 * Bvel v  (double integrator, robotproperty2.m:136-139).
@@ -204,12 +215,46 @@ __device__ __forceinline__ double slack_of(int code, const double *xs, const dou
 }
 
 
+// ---- H = I (the PSGCFS projection, PSGCFS_FANUC.m:117): constraint normals in closed form ----------------
+// A collision row at waypoint i with gradient g is n[k,c] = g_c ((i-k)+1/2) dt^2 for k <= i (CFS_FANUC.m:121 with
+// the double integrator of robotproperty2.m:136-139), a velocity row +-dt for k <= i on its joint.  Products of
+// two normals are sums of small half-integers: formed in integer arithmetic, exact in fp64 and symmetric by
+// construction, so the active set needs neither H^{-1}N in memory nor the family matrices.
+__device__ __forceinline__ double ramp_sum(int a, int m)          // sum_{k=0..m} ((a-k)+1/2)
+{
+    const int M = m + 1;
+    return 0.5 * (double)(M * (2 * a + 1) - m * M);
+}
+__device__ __forceinline__ double ramp_dot(int a, int b, int m)   // sum_{k=0..m} ((a-k)+1/2)((b-k)+1/2)
+{
+    const int M = m + 1;
+    return 0.25 * (double)(M * (2 * a + 1) * (2 * b + 1) - 2 * (a + b + 1) * m * M + 2 * (m * M * (2 * m + 1) / 3));
+}
+template <int NJ>
+__device__ __forceinline__ double gram_ident(int ca, int cp, const double *g, int H, double dt)   // n_a' n_p
+{
+    const int ta = ca >> 16, ia = (ca >> 8) & 0xff, ja = ca & 0xff;
+    const int tp = cp >> 16, ip = (cp >> 8) & 0xff, jp = cp & 0xff;
+    const int m = min(ia, ip);
+    if (ta == CT_COL && tp == CT_COL) {
+        double dot = 0.0;
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) dot += g[(ja * H + ia) * NJ + c] * g[(jp * H + ip) * NJ + c];
+        return dot * ((dt * dt) * (dt * dt) * ramp_dot(ia, ip, m));
+    }
+    if (ta == CT_COL) return g[(ja * H + ia) * NJ + jp] * ((tp == CT_VELP ? -1.0 : 1.0) * (dt * dt * dt) * ramp_sum(ia, m));
+    if (tp == CT_COL) return g[(jp * H + ip) * NJ + ja] * ((ta == CT_VELP ? -1.0 : 1.0) * (dt * dt * dt) * ramp_sum(ip, m));
+    if (ja != jp) return 0.0;
+    return ((ta == tp) ? 1.0 : -1.0) * (dt * dt) * (double)(m + 1);
+}
+
 // ---- one row of the symmetric inverse Gram matrix P: columns [0,PR) in registers, [PR,QB) in global ---
 // tail layout: ptail[(b-PR)*QB + a] (thread a reads consecutive addresses).  Active constraints occupy
 // SLOTS of [0,qhi); a freed slot keeps a (numerically) zero row and column, so whole 8-column chunks are
 // processed unguarded and no column is ever written through a runtime register index.
 template <int PR, int QB>
 struct PRow {
+    static constexpr int TU = 8;         // tail columns loaded per batch
     double v[PR];
     __device__ __forceinline__ void zero(double *ptail, int a, int q)
     {
@@ -228,7 +273,17 @@ struct PRow {
                 for (int jj = 0; jj < 8; ++jj) s += v[b0 + jj] * vec[b0 + jj];
                 __builtin_amdgcn_sched_barrier(0);
             }
-        for (int b = PR; b < q; ++b) s += ptail[(b - PR) * QB + a] * vec[b];
+        // tail columns live in global scratch (L2): keep TU independent loads in flight, a one-at-a-time loop pays the
+        // L2 round trip per column (measured: 45-60 us per step at 120 active rows)
+        int b = PR;
+        for (; b + TU <= q; b += TU) {
+            double t[TU];
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) t[jj] = ptail[(b + jj - PR) * QB + a];
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) s += t[jj] * vec[b + jj];
+        }
+        for (; b < q; ++b) s += ptail[(b - PR) * QB + a] * vec[b];
         return s;
     }
     // P[a][b] += alpha * vec[b]   (vec zero beyond q)
@@ -241,7 +296,15 @@ struct PRow {
                 for (int jj = 0; jj < 8; ++jj) v[b0 + jj] += alpha * vec[b0 + jj];
                 __builtin_amdgcn_sched_barrier(0);
             }
-        for (int b = PR; b < q; ++b) ptail[(b - PR) * QB + a] += alpha * vec[b];
+        int b = PR;
+        for (; b + TU <= q; b += TU) {
+            double t[TU];
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) t[jj] = ptail[(b + jj - PR) * QB + a];
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) ptail[(b + jj - PR) * QB + a] = t[jj] + alpha * vec[b + jj];
+        }
+        for (; b < q; ++b) ptail[(b - PR) * QB + a] += alpha * vec[b];
     }
     // P[a][b] = (P[a][b] + alpha * vec[b]) * mask[b]   (mask is exactly 0 or 1: annihilates a freed column)
     __device__ __forceinline__ void axpy_mask(double alpha, const double *vec, const double *mask, double *ptail, int a, int q)
@@ -253,7 +316,15 @@ struct PRow {
                 for (int jj = 0; jj < 8; ++jj) v[b0 + jj] = (v[b0 + jj] + alpha * vec[b0 + jj]) * mask[b0 + jj];
                 __builtin_amdgcn_sched_barrier(0);
             }
-        for (int b = PR; b < q; ++b) ptail[(b - PR) * QB + a] = (ptail[(b - PR) * QB + a] + alpha * vec[b]) * mask[b];
+        int b = PR;
+        for (; b + TU <= q; b += TU) {
+            double t[TU];
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) t[jj] = ptail[(b + jj - PR) * QB + a];
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) ptail[(b + jj - PR) * QB + a] = (t[jj] + alpha * vec[b + jj]) * mask[b + jj];
+        }
+        for (; b < q; ++b) ptail[(b - PR) * QB + a] = (ptail[(b - PR) * QB + a] + alpha * vec[b]) * mask[b];
     }
     // P[a][b] = alpha * vec[b]
     __device__ __forceinline__ void set_scaled(double alpha, const double *vec, double *ptail, int a, int q)
@@ -277,12 +348,20 @@ struct PRow {
                 for (int jj = 0; jj < 8; ++jj) dst[b0 + jj] = v[b0 + jj];
                 __builtin_amdgcn_sched_barrier(0);
             }
-        for (int b = PR; b < q; ++b) dst[b] = ptail[(b - PR) * QB + a];
+        int b = PR;
+        for (; b + TU <= q; b += TU) {
+            double t[TU];
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) t[jj] = ptail[(b + jj - PR) * QB + a];
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) dst[b + jj] = t[jj];
+        }
+        for (; b < q; ++b) dst[b] = ptail[(b - PR) * QB + a];
     }
 };
 
 struct FusedLayout {      // LDS offsets in doubles, computed identically on host and device
-    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, code, red, small, mx, ptail, lin, y, total_fixed;
+    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, slot, code, red, small, mx, ptail, lin, y, total_fixed;
 };
 __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int QB, int PR)
 {
@@ -313,6 +392,7 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.rho = o; o += QB;
     L.lam = o; o += QB;
     L.prow = o; o += QB;
+    L.slot = o; o += (nobs * H + 4 * HN + 3) / 4;   // constraint -> slot + 1 (0: inactive), ushort; reset at every QP setup
     L.ptail = o;                           // (tail columns of P live in global scratch)
     o = (o + 1) & ~1;
     L.y = o;
@@ -321,7 +401,7 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int NJ, int QB>
+template <int NJ, int QB, bool IDENT>      // IDENT: the QP Hessian is the identity (PSGCFS projection)
 __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(FusedParams P)
 {
     constexpr int NS = 2 * NJ, NVT = nvt(NJ), NE = 2 * NJ + 1;
@@ -338,6 +418,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     int *s_act = reinterpret_cast<int *>(lds + L.act);
     int *s_free = reinterpret_cast<int *>(lds + L.fre);
     unsigned char *s_flag = reinterpret_cast<unsigned char *>(lds + L.flag);
+    unsigned short *s_slot = reinterpret_cast<unsigned short *>(lds + L.slot);
     int *s_code = reinterpret_cast<int *>(lds + L.code);
     double *red = lds + L.red;
     double *s_lim = lds + L.small, *s_v0 = s_lim + NJ, *s_th0 = s_v0 + NJ, *s_margin = s_th0 + 2 * NJ;
@@ -568,6 +649,51 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         int qhi = 0, nfree = 0;                             // slots in use: [0,qhi) minus the free stack
         int npolish = 0;
         // zb = base - sum_a coef[a] * Y[a]   (Y rows [0,QY) in LDS, the rest in global scratch; base == nullptr: zero)
+        // IDENT: zb = (z, Bvel z, Bpos z) with z = base - N coef, N coef in closed form: the active rows of waypoint i
+        // contribute Rp[i] = sum_j coef g_j (position space) and Rv[i] = -+dt coef (velocity space); N coef =
+        // Bpos' Rp + Rv summed over i >= k = suffix sums, done as DPP prefix scans over reversed lanes (lane <-> waypoint
+        // H-1-lane); base == nullptr means w = n_p, evaluated on the fly.  No barrier inside: the caller syncs before and after.
+        auto n_combine = [&](const double *coef, const double *base, int pc_) {
+            const int ptype_ = pc_ >> 16, pi_ = (pc_ >> 8) & 0xff, pj_ = pc_ & 0xff;
+            const bool two = H <= 32;                                   // two joints per wavefront, one per half
+            const int lane = two ? (tid & 31) : (tid & 63);             // waypoint of the rollout part
+            const int iR = H - 1 - lane;                                // waypoint of the suffix part (reversed lanes)
+            const int cstep = two ? 2 * (FT / 64) : FT / 64;
+            for (int c = two ? (tid >> 5) : (tid >> 6); c < NJ; c += cstep) {
+                double Rp = 0.0, Rv = 0.0;
+                if (lane < H) {
+                    const int sp_ = s_slot[nobs * H + iR * NJ + c], sm_ = s_slot[nobs * H + HN + iR * NJ + c];
+                    for (int j0 = 0; j0 < nobs; j0 += 8) {              // slot lookups of eight obstacles in flight
+                        int sl[8];
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) sl[jj] = j0 + jj < nobs ? s_slot[(j0 + jj) * H + iR] : 0;
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj)
+                            if (sl[jj]) Rp += coef[sl[jj] - 1] * s_g[((j0 + jj) * H + iR) * NJ + c];
+                    }
+                    if (sp_) Rv -= dt * coef[sp_ - 1];
+                    if (sm_) Rv += dt * coef[sm_ - 1];
+                }
+                // (N coef)[k] = sum_{i>=k} (((i-k)+1/2) dt^2 Rp[i] + Rv[i]) = dt^2 (S2 - S1/2) + V1 with S1 = suffix(Rp), S2 = suffix(S1),
+                // V1 = suffix(Rv): two scans, the second one carries dt^2 S1 + Rv
+                const double S1 = two ? half_scan_incl(Rp) : wave_scan_incl(Rp);
+                const double cmb = (dt * dt) * S1 + Rv;
+                const double S2V = two ? half_scan_incl(cmb) : wave_scan_incl(cmb);
+                const double nr_rev = S2V - (0.5 * dt * dt) * S1;       // (N coef)[H-1-lane, c]
+                const int src = (lane < H ? H - 1 - lane : lane) + (two ? (tid & 32) : 0);
+                const double nr = __shfl(nr_rev, src, 64);
+                double z0 = 0.0;
+                if (lane < H) {
+                    if (base) z0 = base[lane * NJ + c];
+                    else if (ptype_ == CT_COL) z0 = lane <= pi_ ? s_g[(pj_ * H + pi_) * NJ + c] * ((dt * dt) * ((double)(pi_ - lane) + 0.5)) : 0.0;
+                    else z0 = (c == pj_ && lane <= pi_) ? (ptype_ == CT_VELP ? -dt : dt) : 0.0;
+                    z0 -= nr;
+                }
+                const double sv = dt * (two ? half_scan_incl(z0) : wave_scan_incl(z0));
+                const double spo = dt * (two ? half_scan_incl(sv) : wave_scan_incl(sv)) - (0.5 * dt) * sv;
+                if (lane < H) { zb[lane * NJ + c] = z0; zb[HN + lane * NJ + c] = sv; zb[2 * HN + lane * NJ + c] = spo; }
+            }
+        };
         auto y_combine = [&](const double *coef, const double *base) {
             const int qa = min(qhi, QY);
             for (int k = tid; k < HN; k += FT) {
@@ -580,11 +706,12 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     z3 -= coef[a + 3] * s_Y[(a + 3) * HN + k];
                 }
                 for (; a < qa; ++a) z0 -= coef[a] * s_Y[a * HN + k];
-                for (a = qa; a + 4 <= qhi; a += 4) {
-                    z0 -= coef[a] * Yg[(size_t)a * nn + k];
-                    z1 -= coef[a + 1] * Yg[(size_t)(a + 1) * nn + k];
-                    z2 -= coef[a + 2] * Yg[(size_t)(a + 2) * nn + k];
-                    z3 -= coef[a + 3] * Yg[(size_t)(a + 3) * nn + k];
+                for (a = qa; a + 8 <= qhi; a += 8) {         // rows beyond the LDS capacity: eight L2 loads in flight
+                    double t[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) t[jj] = Yg[(size_t)(a + jj) * nn + k];
+                    z0 -= coef[a] * t[0]; z1 -= coef[a + 1] * t[1]; z2 -= coef[a + 2] * t[2]; z3 -= coef[a + 3] * t[3];
+                    z0 -= coef[a + 4] * t[4]; z1 -= coef[a + 5] * t[5]; z2 -= coef[a + 6] * t[6]; z3 -= coef[a + 7] * t[7];
                 }
                 for (; a < qhi; ++a) z0 -= coef[a] * Yg[(size_t)a * nn + k];
                 zb[k] = (z0 + z1) + (z2 + z3);
@@ -593,7 +720,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         if (!skip) {
             // rhs = (d - margin) - Diff'*Bj(1:nj,:)*u   (CFS_FANUC.m:119-120), with Bpos*u from a rollout of u
             for (int k = tid; k < HN; k += FT) wb[k] = s_u[k];
-            for (int e = tid; e < ncon; e += FT) s_flag[e] = 0;
+            for (int e = tid; e < ncon; e += FT) { s_flag[e] = 0; s_slot[e] = 0; }
             Pr.zero(s_pt, tid, 0);
             if (tid < QB) { s_d[tid] = 0.0; s_r[tid] = 0.0; s_rho[tid] = 0.0; s_prow[tid] = 0.0; s_lam[tid] = 0.0; s_act[tid] = -1; }
             __syncthreads();
@@ -680,7 +807,15 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     if (!polish && ++iters > maxit) { qp_status = QP_NUMERIC; break; }
                     double spp = 0.0;
                     const int myact = tid < qhi ? s_act[tid] : -1;
-                    if (!polish) {
+                    if (!polish && IDENT) {
+                        // H = I: w = n_p; d = N'n_p and n_p'n_p straight from the closed form (exactly symmetric products)
+                        spp = gram_ident<NJ>(pc, pc, s_g, H, dt);
+                        if (tid < qhi) s_d[tid] = myact >= 0 ? gram_ident<NJ>(myact, pc, s_g, H, dt) : 0.0;
+                        __syncthreads();
+                        if (tid < qhi) s_r[tid] = myact >= 0 ? Pr.dot(s_d, s_pt, tid, qhi) : 0.0;
+                        __syncthreads();
+                    }
+                    if (!polish && !IDENT) {
                     // w = H^{-1} n_p together with its rollouts (Bvel w, Bpos w): a gather of <= NJ columns of the
                     // family matrices and of their precomputed rollouts -- no prefix sums, one barrier
                     for (int k = tid; k < HN; k += FT) {
@@ -721,10 +856,15 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     bool enter_at_correction = polish;                 // the projection starts at "dr = P rho" with rho = active slacks
                     for (int pass = 0; pass < 4; ++pass) {
                         if (!enter_at_correction) {
+                        if (IDENT) {
+                            n_combine(pass == 0 ? s_r : s_rho, pass == 0 ? nullptr : zb, pc);
+                            __syncthreads();
+                        } else {
                         y_combine(pass == 0 ? s_r : s_rho, pass == 0 ? wb : zb);       // pass>0: correction dr held in s_rho
                         __syncthreads();
                         roll_lds<NJ>(zb, H, dt, tid);
                         __syncthreads();
+                        }
                         if (polish) break;                             // zb = (x, Bvel x, Bpos x) after the projection
                         delta = ndot<NJ>(pc, zb, s_g, H);              // n_p'z
                         if (qhi == nfree) break;                       // empty active set: nothing to refine, t1 = inf
@@ -815,9 +955,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         __syncthreads();
                         if (tid < qhi && myact >= 0) Pr.axpy(s_r[tid] * inv, s_r, s_pt, tid, qn);
                         else if (tid == slot) Pr.set_scaled(-inv, s_r, s_pt, tid, qn);
-                        if (slot < QY) { for (int k = tid; k < HN; k += FT) s_Y[slot * HN + k] = wb[k]; }
-                        else { for (int k = tid; k < HN; k += FT) Yg[(size_t)slot * nn + k] = wb[k]; }
-                        if (tid == 0) { s_act[slot] = pc; s_lam[slot] = lam_p; s_flag[pidx] = 1; }
+                        if (!IDENT) {
+                            if (slot < QY) { for (int k = tid; k < HN; k += FT) s_Y[slot * HN + k] = wb[k]; }
+                            else { for (int k = tid; k < HN; k += FT) Yg[(size_t)slot * nn + k] = wb[k]; }
+                        }
+                        if (tid == 0) { s_act[slot] = pc; s_lam[slot] = lam_p; s_flag[pidx] = 1; s_slot[pidx] = (unsigned short)(slot + 1); }
                         if (nfree > 0) --nfree;
                         qhi = qn;
                         __syncthreads();
@@ -840,7 +982,9 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                             s_lam[l] = 0.0;
                             s_free[nfree] = l;
                             const int gt = gone >> 16, gi = (gone >> 8) & 0xff, gj = gone & 0xff;
-                            s_flag[gt == CT_COL ? gj * H + gi : nobs * H + (gt - 1) * HN + gi * NJ + gj] = 0;
+                            const int gidx = gt == CT_COL ? gj * H + gi : nobs * H + (gt - 1) * HN + gi * NJ + gj;
+                            s_flag[gidx] = 0;
+                            s_slot[gidx] = 0;
                         }
                         ++nfree;
                         __syncthreads();
@@ -950,12 +1094,12 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     if (P.stamps && tid == 0) for (int k = 0; k < 12; ++k) P.stamps[(size_t)b * 12 + k] = s_acc[k];
 }
 
-template <int NJ, int QB>
-hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
+template <int NJ, int QB, bool IDENT>
+hipError_t launch_fused_inst2(const FusedParams &p, size_t lds, hipStream_t s)
 {
     // the function attribute is per device (handles may live on several GPUs of one process: cfs_set_device)
     static std::atomic<unsigned long long> attr_set{0ull};
-    auto kern = cfs_solve_fused_kernel<NJ, QB>;
+    auto kern = cfs_solve_fused_kernel<NJ, QB, IDENT>;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -966,6 +1110,23 @@ hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
     }
     hipLaunchKernelGGL(kern, dim3(p.B), dim3(FT), lds, s, p);
     return hipGetLastError();
+}
+
+// CFS_IDENT_SET: which Hessians this tier is compiled for (0: QQ only, 1: identity only, 2: both) -- compile time, not a dual path
+#ifndef CFS_IDENT_SET
+#define CFS_IDENT_SET 2
+#endif
+template <int NJ, int QB>
+hipError_t launch_fused_inst(const FusedParams &p, size_t lds, hipStream_t s)
+{
+    const bool ident = p.mode == CFS_MODE_PSGCFS;
+#if CFS_IDENT_SET != 0
+    if (ident) return launch_fused_inst2<NJ, QB, true>(p, lds, s);
+#endif
+#if CFS_IDENT_SET != 1
+    if (!ident) return launch_fused_inst2<NJ, QB, false>(p, lds, s);
+#endif
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -994,9 +1155,10 @@ hipError_t CFS_CAT(launch_fused, CFS_VARIANT)(int nj, FusedParams p, hipStream_t
     const int QB = nn <= 96 ? 96 : (nn <= 160 ? 160 : 256);
     const FusedLayout L = fused_layout(nj, p.H, p.nobs, QB, QB < CFS_PR ? QB : CFS_PR);
     const size_t avail = (160 * 1024 / CFS_WG_PER_CU) / 8 - 64;   // doubles per workgroup, small safety margin
-    if ((size_t)L.total_fixed + 4 * nn > avail) return hipErrorInvalidValue;
+    const bool ident = p.mode == CFS_MODE_PSGCFS;          // H = I: no Y rows at all (closed-form normals)
+    if ((size_t)L.total_fixed + (ident ? 0 : 4 * nn) > avail) return hipErrorInvalidValue;
     const size_t region = avail - L.total_fixed;
-    int qy = (int)(region / nn);
+    int qy = ident ? 0 : (int)(region / nn);
     if (qy > nn) qy = nn;
     const size_t per_wp = lin_doubles_per_wp(nj, p.nobs);
     int w = (int)((avail - L.lin) / per_wp);   // the linearisation may use the QP's work vectors too (layout)
