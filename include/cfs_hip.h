@@ -137,6 +137,27 @@ int cfs_set_device(int device);             /* device used by subsequently creat
 int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out);
 void cfs_problem_destroy(cfs_problem *p);
 
+/* The same from the WEIGHTS of the drivers' cost instead of the assembled matrices (row f2 of the scope table): the library
+ * builds Aaug/Baug (double integrator of robot.A/robot.B), Q = [Qp q_cross*I; q_cross*I Qv], Qaug = blkdiag(w_stage*Q, ...,
+ * w_terminal*Q), R = kron(I_H, Rblk), R = R + R', QQ = Baug'*Qaug*Baug + cR*R exactly as main_FANUC.m:64-97 (RRTstar_CFS.m:
+ * 124-157, main_2L.m:69-93) do, the state-cost terms cfs_set_state_cost would otherwise be given (so cfs_build_terms_device
+ * works at once), and, when desc->alpha == 0, alpha = 1/max(svd(QQ)) (main_FANUC.m:120).  desc->QQ / Aaug / Baug are ignored.
+ * Neither QQ nor Qaug crosses the boundary; cfs_problem_family reads back what was built.  Because the structure of QQ is
+ * known, QQ*u inside the solver (get_cost, Lib/EVAL.m:51-53; dcostArm_f, Lib/PSGCFS_FANUC.m:131-133) is evaluated through
+ * Baug and the 2nj x 2nj blocks instead of the dense nn x nn matrix. */
+typedef struct cfs_cost_weights {
+    const double *Qp;   /* njoint x njoint column-major: Q(1:nj,1:nj)           (main_FANUC.m:66-70)   */
+    const double *Qv;   /* njoint x njoint:              Q(nj+1:2nj,nj+1:2nj)   (main_FANUC.m:73-77)   */
+    double q_cross;     /* Q(1:nj,nj+1:2nj) = Q(nj+1:2nj,1:nj) = q_cross*eye    (0.1, main_FANUC.m:71-72) */
+    double w_stage;     /* Qaug block of waypoints 1..H-1 = Q*w_stage           (0.1, main_FANUC.m:81) */
+    double w_terminal;  /* Qaug block of waypoint H      = Q*w_terminal         (10000, main_FANUC.m:83) */
+    const double *Rblk; /* njoint x njoint column-major                         (main_FANUC.m:90-94)   */
+    double cR;          /* QQ = Baug'*Qaug*Baug + R.*cR                         (50 | 10 | 0.1, :97)   */
+} cfs_cost_weights;
+int cfs_problem_create_from_weights(const cfs_problem_desc *desc, const cfs_cost_weights *w, cfs_problem **out);
+/* what the handle was built with: QQ (nn x nn column-major, HOST pointer, may be NULL) and alpha (may be NULL) */
+int cfs_problem_family(const cfs_problem *p, double *QQ, double *alpha);
+
 /* ---- whole solve -----------------------------------------------------------------------------
  * replaces: self.optimizer() (Lib/CFS_FANUC.m:62-79, Lib/PSGCFS_FANUC.m:65-82) for B problems.
  * Host pointers; copies in, runs all outer iterations on the device, copies out, synchronises. */

@@ -70,6 +70,18 @@ class cfs_problem_desc(C.Structure):
     ]
 
 
+class cfs_cost_weights(C.Structure):
+    _fields_ = [
+        ("Qp", C.c_void_p),
+        ("Qv", C.c_void_p),
+        ("q_cross", C.c_double),
+        ("w_stage", C.c_double),
+        ("w_terminal", C.c_double),
+        ("Rblk", C.c_void_p),
+        ("cR", C.c_double),
+    ]
+
+
 class cfs_batch_in(C.Structure):
     _fields_ = [
         ("B", C.c_int),
@@ -105,6 +117,8 @@ SYMBOLS = [
     ("cfs_set_device", C.c_int, [C.c_int]),
     ("cfs_problem_create", C.c_int, [C.POINTER(cfs_problem_desc), C.POINTER(_P)]),
     ("cfs_problem_destroy", None, [_P]),
+    ("cfs_problem_create_from_weights", C.c_int, [C.POINTER(cfs_problem_desc), C.POINTER(cfs_cost_weights), C.POINTER(_P)]),
+    ("cfs_problem_family", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     ("cfs_solve_batch", C.c_int, [_P, C.POINTER(cfs_batch_in), C.POINTER(cfs_batch_out)]),
     ("cfs_solve_batch_device", C.c_int, [_P, C.POINTER(cfs_batch_in), C.POINTER(cfs_batch_out), _P]),
     ("cfs_set_state_cost", C.c_int, [_P, _P]),

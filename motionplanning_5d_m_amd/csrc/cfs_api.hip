@@ -172,6 +172,8 @@ struct cfs_problem {
     DevBuf<DevRobot> rb;
     DevBuf<double> QQ, Hinv, Hq, M1n, M2n, lim, maxin, margin;
     DevBuf<double> F1, F2, Cq;   // per-problem cost terms from (x0, xg), set by cfs_set_state_cost
+    DevBuf<DevCost> cost;        // structure of QQ (handles created from the cost weights)
+    std::vector<double> QQ_host; // what cfs_problem_family hands back
     DevBuf<double> Mr[6];   // rollouts (Bvel*, Bpos*) of the columns of M1n, M2n, Hq
     // workspace (max_batch problems)
     DevBuf<double> x0, qu, dist, grad, Yg, Pt, u_hist, qu_hist;
@@ -192,7 +194,7 @@ struct cfs_problem {
         rb.release(); QQ.release(); Hinv.release(); Hq.release();
         M1n.release(); M2n.release(); Pt.release(); u_hist.release(); qu_hist.release();
         for (auto &m : Mr) m.release();
-        F1.release(); F2.release(); Cq.release();
+        F1.release(); F2.release(); Cq.release(); cost.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
         grad.release(); Yg.release(); noise_row.release();
         linkid.release(); meshes_d.release(); st_cost.release(); st_done.release();
@@ -426,6 +428,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     cfs_problem *p = new (std::nothrow) cfs_problem();
     if (!p) return fail(CFS_ERR_ALLOC, "out of host memory");
     p->d = *desc;
+    p->QQ_host.assign(desc->QQ, desc->QQ + (size_t)nn * nn);
     p->d.QQ = p->d.Aaug = p->d.Baug = p->d.lim = p->d.MAX_input = p->d.margin = nullptr;
     p->device = g_device;
     p->nn = nn; p->ns = ns; p->nx = nx; p->lmax_vel = lmax_vel; p->lmax_H = lmax_H;
@@ -466,6 +469,123 @@ void cfs_problem_destroy(cfs_problem *p)
     delete p;
 }
 
+int cfs_problem_family(const cfs_problem *p, double *QQ, double *alpha)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    if (QQ) memcpy(QQ, p->QQ_host.data(), p->QQ_host.size() * sizeof(double));
+    if (alpha) *alpha = p->d.alpha;
+    return CFS_SUCCESS;
+}
+
+// largest eigenvalue of a symmetric matrix by cyclic Jacobi rotations (once per family, n <= 384)
+static double sym_lambda_max(int n, std::vector<double> A)
+{
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) (i == j ? dia : off) += A[i + (size_t)j * n] * A[i + (size_t)j * n];
+        if (off <= 1e-30 * dia) break;
+        for (int p_ = 0; p_ < n - 1; ++p_)
+            for (int q_ = p_ + 1; q_ < n; ++q_) {
+                const double apq = A[p_ + (size_t)q_ * n];
+                if (apq == 0.0) continue;
+                const double theta = (A[q_ + (size_t)q_ * n] - A[p_ + (size_t)p_ * n]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) {               // columns p, q
+                    const double akp = A[k + (size_t)p_ * n], akq = A[k + (size_t)q_ * n];
+                    A[k + (size_t)p_ * n] = c * akp - sn * akq;
+                    A[k + (size_t)q_ * n] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {               // rows p, q
+                    const double apk = A[p_ + (size_t)k * n], aqk = A[q_ + (size_t)k * n];
+                    A[p_ + (size_t)k * n] = c * apk - sn * aqk;
+                    A[q_ + (size_t)k * n] = sn * apk + c * aqk;
+                }
+            }
+    }
+    double m = A[0];
+    for (int i = 1; i < n; ++i) m = std::max(m, A[i + (size_t)i * n]);
+    return m;
+}
+
+int cfs_problem_create_from_weights(const cfs_problem_desc *desc, const cfs_cost_weights *w, cfs_problem **out)
+{
+    if (!desc || !w || !out) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    if (!w->Qp || !w->Qv || !w->Rblk) return fail(CFS_ERR_INVALID_ARG, "Qp/Qv/Rblk must be given");
+    const int nj = desc->njoint, H = desc->H;
+    if (nj < 2 || nj > 6 || H < 1 || H > CFS_MAX_H) return fail(CFS_ERR_INVALID_ARG, "njoint %d / H %d unsupported", nj, H);
+    const double dt = desc->robot.delta_t;
+    if (!(dt > 0)) return fail(CFS_ERR_INVALID_ARG, "robot.delta_t must be positive");
+    const int ns = 2 * nj, nn = H * nj, nx = H * ns;
+    // Q = [Qp qc*I; qc*I Qv] (main_FANUC.m:65-77), Qaug = blkdiag(Q*w_stage, ..., Q*w_terminal) (:81-84)
+    std::vector<double> Q((size_t)ns * ns, 0.0), Qaug((size_t)nx * nx, 0.0);
+    for (int c = 0; c < nj; ++c)
+        for (int r = 0; r < nj; ++r) {
+            Q[r + (size_t)c * ns] = w->Qp[r + c * nj];
+            Q[(nj + r) + (size_t)(nj + c) * ns] = w->Qv[r + c * nj];
+            if (r == c) { Q[r + (size_t)(nj + c) * ns] = w->q_cross; Q[(nj + r) + (size_t)c * ns] = w->q_cross; }
+        }
+    for (int i = 0; i < H; ++i) {
+        const double wi = i == H - 1 ? w->w_terminal : w->w_stage;
+        for (int c = 0; c < ns; ++c)
+            for (int r = 0; r < ns; ++r) Qaug[(i * ns + r) + (size_t)(i * ns + c) * nx] = Q[r + (size_t)c * ns] * wi;
+    }
+    // T = Qaug*Baug (block rows), QQ = Baug'*T + cR*(R + R')  (:96-97); Baug(i,k) = [((i-k)+1/2) dt^2 I; dt I] for k <= i
+    std::vector<double> T((size_t)nx * nn, 0.0), QQ((size_t)nn * nn, 0.0);
+    for (int k = 0; k < H; ++k)
+        for (int c = 0; c < nj; ++c) {
+            const int col = k * nj + c;
+            for (int i = k; i < H; ++i) {
+                const double bp = ((double)(i - k) + 0.5) * dt * dt, bv = dt;
+                for (int r = 0; r < ns; ++r)
+                    T[(i * ns + r) + (size_t)col * nx] = Qaug[(i * ns + r) + (size_t)(i * ns + c) * nx] * bp + Qaug[(i * ns + r) + (size_t)(i * ns + nj + c) * nx] * bv;
+            }
+        }
+    for (int col = 0; col < nn; ++col)
+        for (int k = 0; k < H; ++k)
+            for (int c = 0; c < nj; ++c) {
+                double sacc = 0.0;
+                for (int i = k; i < H; ++i)
+                    sacc += (((double)(i - k) + 0.5) * dt * dt) * T[(i * ns + c) + (size_t)col * nx] + dt * T[(i * ns + nj + c) + (size_t)col * nx];
+                QQ[(k * nj + c) + (size_t)col * nn] = sacc;
+            }
+    DevCost hc;
+    memset(&hc, 0, sizeof hc);
+    for (int c = 0; c < nj; ++c)
+        for (int r = 0; r < nj; ++r) {
+            hc.Qp[r + c * nj] = w->Qp[r + c * nj];
+            hc.Qv[r + c * nj] = w->Qv[r + c * nj];
+            hc.Rs[r + c * nj] = (w->Rblk[r + c * nj] + w->Rblk[c + r * nj]) * w->cR;
+        }
+    hc.qc = w->q_cross; hc.ws = w->w_stage; hc.wt = w->w_terminal;
+    for (int i = 0; i < H; ++i)
+        for (int c = 0; c < nj; ++c)
+            for (int r = 0; r < nj; ++r) QQ[(i * nj + r) + (size_t)(i * nj + c) * nn] += hc.Rs[r + c * nj];
+    cfs_problem_desc d2 = *desc;
+    d2.QQ = QQ.data();
+    d2.Aaug = d2.Baug = nullptr;                           // implied: the double integrator
+    if (d2.alpha == 0.0 && d2.mode == CFS_MODE_PSGCFS) {   // alpha = 1/max(svd(QQ))  (main_FANUC.m:120)
+        std::vector<double> sym((size_t)nn * nn);
+        for (int j = 0; j < nn; ++j)
+            for (int i = 0; i < nn; ++i) sym[i + (size_t)j * nn] = 0.5 * (QQ[i + (size_t)j * nn] + QQ[j + (size_t)i * nn]);
+        d2.alpha = 1.0 / sym_lambda_max(nn, sym);
+    }
+    cfs_problem *p = nullptr;
+    int rc = cfs_problem_create(&d2, &p);
+    if (rc) return rc;
+    rc = cfs_set_state_cost(p, Qaug.data());
+    if (rc == CFS_SUCCESS) {
+        hipError_t e = p->cost.alloc(1);
+        if (e == hipSuccess) e = hipMemcpy(p->cost.p, &hc, sizeof hc, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(CFS_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
+    }
+    if (rc) { cfs_problem_destroy(p); return rc; }
+    *out = p;
+    return CFS_SUCCESS;
+}
+
 // family-level fields of the fused kernel's parameter block (everything that does not change across a batch)
 static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
 {
@@ -473,7 +593,7 @@ static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
     fp.rb = p->rb.p; fp.B = B; fp.H = p->d.H; fp.nobs = p->d.nobs; fp.mode = p->d.mode;
     fp.has_bounds = p->d.mode == CFS_MODE_CFS; fp.max_o_iter = p->d.MAX_O_ITER;
     fp.dt = p->d.robot.delta_t; fp.alpha = p->d.alpha; fp.epsilon_O = p->d.epsilon_O; fp.lmax_vel = p->lmax_vel; fp.lmax_H = p->lmax_H;
-    fp.M1 = p->M1n.p; fp.M2 = p->M2n.p; fp.M3 = p->Hq.p; fp.QQ = p->QQ.p;
+    fp.M1 = p->M1n.p; fp.M2 = p->M2n.p; fp.M3 = p->Hq.p; fp.QQ = p->QQ.p; fp.cost = p->cost.p;
     fp.M1v = p->Mr[0].p; fp.M1p = p->Mr[1].p; fp.M2v = p->Mr[2].p; fp.M2p = p->Mr[3].p; fp.M3v = p->Mr[4].p; fp.M3p = p->Mr[5].p;
     fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
     fp.x0 = p->x0.p;

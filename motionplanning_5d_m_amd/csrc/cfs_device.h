@@ -27,6 +27,14 @@ struct DevRobot {
 };
 static_assert(sizeof(DevRobot) % 8 == 0, "DevRobot is copied to LDS as doubles");
 
+// Structure of QQ = Baug'*Qaug*Baug + cR*(R+R') when the handle was created from the cost weights (cfs_problem_create_from_weights):
+// QQ*u = Bpos'(w_i (Qp p_i + qc v_i)) + Bvel'(w_i (qc p_i + Qv v_i)) + Rs u_i with (p, v) = (Bpos u, Bvel u), w_i = w_stage | w_terminal
+struct DevCost {
+    double Qp[36], Qv[36], Rs[36];   // nj x nj column-major (leading dimension nj): Qp, Qv, cR*(Rblk + Rblk')
+    double qc, ws, wt, pad;
+};
+static_assert(sizeof(DevCost) % 8 == 0, "DevCost is read as doubles");
+
 // ---- plain dist_arm and the dense constraint writer (cfs_geom.hip) ----------------------------
 struct DistArmParams {
     const DevRobot *rb;
@@ -75,6 +83,7 @@ struct FusedParams {
     const double *M1, *M2, *M3;  // nn x nn column-major: H^{-1}Bpos', H^{-1}Bvel', H^{-1} (natural row order)
     const double *M1v, *M1p, *M2v, *M2p, *M3v, *M3p;   // Bvel* and Bpos* of every column of M1, M2, M3
     const double *QQ;            // raw sys_info.QQ
+    const DevCost *cost;         // structure of QQ (null: dense QQ only)
     const double *lim, *maxin, *margin;
     const double *x_init, *xR1, *ff, *caug, *obs, *noise;
     const double *x0;            // CFS: -H^{-1} ff  (B x nn)

@@ -361,7 +361,7 @@ struct PRow {
 };
 
 struct FusedLayout {      // LDS offsets in doubles, computed identically on host and device
-    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, slot, code, red, small, mx, ptail, lin, y, total_fixed;
+    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, slot, code, red, small, mx, cost, ptail, lin, y, total_fixed;
 };
 __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int QB, int PR)
 {
@@ -383,6 +383,7 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.red = o; o += 32;
     L.small = o; o += 4 * NJ + nobs;       // lim, v0, theta0 (2NJ), margin
     L.mx = o; o += HN;                     // MAX_input
+    L.cost = o; o += (int)(sizeof(DevCost) / 8);   // structure of QQ (handles created from the cost weights)
     o = (o + 1) & ~1;
     L.lin = o;                             // linearisation scratch starts here: it may overwrite the QP's work vectors below
     L.wb = o; o += 3 * HN;
@@ -453,6 +454,10 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             s_th0[tid] = P.xR1[(size_t)b * NS + tid];
         }
         if (tid < nobs) s_margin[tid] = P.margin[tid];
+        if (P.cost) {
+            const double *csrc = reinterpret_cast<const double *>(P.cost);
+            for (int e = tid; e < (int)(sizeof(DevCost) / 8); e += FT) lds[L.cost + e] = csrc[e];
+        }
     }
     __syncthreads();
     unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(red + 20);   // 12 phase accumulators (developer aid)
@@ -1051,6 +1056,44 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             if (tid == 0) P.e_u_all[(size_t)b * P.max_o_iter + (iter_O - 1)] = sqrt(du2);
         } else {
             double cpart = 0.0;
+            if (P.cost) {
+                // QQ = Baug'*Qaug*Baug + cR*(R+R') (main_FANUC.m:96-97) applied through its factors: with (p, v) = (Bpos u, Bvel u)
+                // already in xs, QQ*u = Bpos'(w_i (Qp p_i + qc v_i)) + Bvel'(w_i (qc p_i + Qv v_i)) + Rs u_i; Bpos', Bvel' are suffix
+                // sums along the horizon (DPP scans over reversed lanes) -- no pass over the dense nn x nn matrix
+                const DevCost *ck = reinterpret_cast<const DevCost *>(lds + L.cost);
+                const bool two = H <= 32;
+                const int lane = two ? (tid & 31) : (tid & 63), iR = H - 1 - lane;
+                const int cstep = two ? 2 * (FT / 64) : FT / 64;
+                for (int c = two ? (tid >> 5) : (tid >> 6); c < NJ; c += cstep) {
+                    double Rp = 0.0, Rv = 0.0;
+                    if (lane < H) {
+                        const double wi = iR == H - 1 ? ck->wt : ck->ws;
+                        double ap = 0.0, av = 0.0;
+#pragma unroll
+                        for (int c2 = 0; c2 < NJ; ++c2) {
+                            ap += ck->Qp[c + c2 * NJ] * xs[2 * HN + iR * NJ + c2];
+                            av += ck->Qv[c + c2 * NJ] * xs[HN + iR * NJ + c2];
+                        }
+                        Rp = wi * (ap + ck->qc * xs[HN + iR * NJ + c]);
+                        Rv = dt * (wi * (ck->qc * xs[2 * HN + iR * NJ + c] + av));
+                    }
+                    const double S1 = two ? half_scan_incl(Rp) : wave_scan_incl(Rp);
+                    const double cmb = (dt * dt) * S1 + Rv;
+                    const double S2V = two ? half_scan_incl(cmb) : wave_scan_incl(cmb);
+                    const double y_rev = S2V - (0.5 * dt * dt) * S1;
+                    const int src = (lane < H ? H - 1 - lane : lane) + (two ? (tid & 32) : 0);
+                    const double y = __shfl(y_rev, src, 64);
+                    if (lane < H) {
+                        const int k = lane * NJ + c;
+                        double ru = 0.0;
+#pragma unroll
+                        for (int c2 = 0; c2 < NJ; ++c2) ru += ck->Rs[c + c2 * NJ] * s_u[lane * NJ + c2];
+                        const double sq = y + ru;
+                        s_qu[k] = sq;
+                        cpart += s_u[k] * (0.5 * sq + P.ff[(size_t)b * nn + k]);
+                    }
+                }
+            } else
             for (int k = tid; k < HN; k += FT) {
                 double sa[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                 int c = 0;

@@ -53,7 +53,10 @@ class CFSBatch:
     """A problem family (robot, horizon, cost matrix, limits, obstacle count and margins) on one GPU,
     solving batches of problems that differ in start/goal (x_init, xR1, ff, caug), obstacles and noise."""
 
-    def __init__(self, sys_info, nobs, margin, mode="CFS", max_batch=1, device=None, check_dynamics=True):
+    def __init__(self, sys_info, nobs, margin, mode="CFS", max_batch=1, device=None, check_dynamics=True, use_weights="auto"):
+        """use_weights: True -> cfs_problem_create_from_weights(sys_info.weights) (the library assembles QQ, Qaug and alpha
+        itself: neither crosses the boundary); False -> cfs_problem_create(sys_info.QQ, ...); "auto" -> True when sys_info
+        carries the weights its matrices were assembled from (sysinfo.build_sys_info records them)."""
         s = sys_info
         self.mode = mode
         self.H, self.nj = int(s.H), int(s.njoint)
@@ -69,10 +72,17 @@ class CFSBatch:
         d.robot = to_c_robot(s.robot)
         d.mode = _lib.MODE[mode]
         d.H, d.njoint, d.nobs = self.H, self.nj, self.nobs
-        keep = [np.asfortranarray(s.QQ, dtype=np.float64), _f64(s.lim), _f64(np.asarray(margin, float).reshape(-1))]
+        wts = getattr(s, "weights", None)
+        self.from_weights = bool(use_weights) and wts is not None if use_weights == "auto" else bool(use_weights)
+        if self.from_weights and wts is None:
+            raise ValueError("use_weights=True needs sys_info.weights")
+        keep = [None if self.from_weights else np.asfortranarray(s.QQ, dtype=np.float64), _f64(s.lim),
+                _f64(np.asarray(margin, float).reshape(-1))]
         d.QQ, d.lim, d.margin = _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2])
         if keep[2].size != self.nobs:
             raise ValueError("margin must have one entry per obstacle")
+        if self.from_weights:
+            check_dynamics = False                       # Aaug / Baug are implied (and built) by the library
         if check_dynamics and getattr(s, "Aaug", None) is not None:
             keep.append(np.asfortranarray(s.Aaug, dtype=np.float64))
             d.Aaug = _ptr(keep[-1])
@@ -85,9 +95,24 @@ class CFSBatch:
         d.epsilon_O, d.MAX_O_ITER, d.alpha = float(s.epsilon_O), self.K, float(getattr(s, "alpha", 0.0))
         d.max_batch = self.max_batch
         h = C.c_void_p()
-        _lib.check(lib.cfs_problem_create(C.byref(d), C.byref(h)))
+        if self.from_weights:
+            w = _lib.cfs_cost_weights()
+            keep += [np.asfortranarray(wts["Qp"], dtype=np.float64), np.asfortranarray(wts["Qv"], dtype=np.float64),
+                     np.asfortranarray(wts["Rblk"], dtype=np.float64)]
+            w.Qp, w.Qv, w.Rblk = _ptr(keep[-3]), _ptr(keep[-2]), _ptr(keep[-1])
+            w.q_cross, w.w_stage, w.w_terminal, w.cR = float(wts["q_cross"]), float(wts["w_stage"]), float(wts["w_terminal"]), float(wts["cR"])
+            _lib.check(lib.cfs_problem_create_from_weights(C.byref(d), C.byref(w), C.byref(h)))
+        else:
+            _lib.check(lib.cfs_problem_create(C.byref(d), C.byref(h)))
         self._h = h
         self._lib = lib
+
+    def family(self):
+        """(QQ, alpha) the handle was built with (cfs_problem_family)."""
+        QQ = np.zeros((self.nn, self.nn), order="F")
+        a = C.c_double(0.0)
+        _lib.check(self._lib.cfs_problem_family(self._h, _ptr(QQ), C.byref(a)))
+        return QQ, a.value
 
     def close(self):
         if getattr(self, "_h", None):

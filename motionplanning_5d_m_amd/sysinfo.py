@@ -68,6 +68,9 @@ def build_sys_info(robot, njoint, horizon, x0, xg, x_init, *, Qp, Qv, Rblk, cR, 
     s.lim = np.asarray(lim, float).reshape(-1)
     s.epsilon_O, s.MAX_O_ITER = float(epsilon_O), int(MAX_O_ITER)
     s.MAX_input = np.tile(np.asarray(max_input_blk, float).reshape(-1), H)  # :127
+    # the weights the matrices above were assembled from: what cfs_problem_create_from_weights takes instead of QQ / Qaug
+    s.weights = dict(Qp=np.asarray(Qp, float), Qv=np.asarray(Qv, float), q_cross=0.1, w_stage=0.1, w_terminal=10000.0,
+                     Rblk=np.asarray(Rblk, float), cR=float(cR))
     return s
 
 

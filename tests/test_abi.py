@@ -46,7 +46,7 @@ def test_argument_validation_and_no_device_error():
     s2 = copy.copy(s); s2.Baug = s.Baug.copy(); s2.Baug[3, 0] += 1e-3
     if pkg.device_count() == 0:
         with pytest.raises(pkg.CfsError) as e:
-            pkg.CFSBatch(s2, 1, [0.25])
+            pkg.CFSBatch(s2, 1, [0.25], use_weights=False)
         assert e.value.code == -5                      # CFS_ERR_DYNAMICS is detected before touching the device
         with pytest.raises(pkg.CfsError) as e:
             pkg.CFS_FANUC(obs, s, R)
@@ -56,8 +56,15 @@ def test_argument_validation_and_no_device_error():
         assert e.value.code == -2
     s3 = copy.copy(s); s3.QQ = -s.QQ
     with pytest.raises(pkg.CfsError) as e:
-        pkg.CFSBatch(s3, 1, [0.25])
+        pkg.CFSBatch(s3, 1, [0.25], use_weights=False)
     assert e.value.code in (-4, -2)                    # not SPD (or no device, whichever is checked first)
+    s4 = copy.copy(s); s4.weights = dict(s.weights, cR=-1e6)
+    with pytest.raises(pkg.CfsError) as e:
+        pkg.CFSBatch(s4, 1, [0.25], use_weights=True)  # cfs_problem_create_from_weights: the assembled QQ is indefinite
+    assert e.value.code in (-4, -2)
+    with pytest.raises(ValueError):
+        s5 = copy.copy(s); del s5.weights
+        pkg.CFSBatch(s5, 1, [0.25], use_weights=True)
 
 
 def test_product_does_not_import_the_oracle():

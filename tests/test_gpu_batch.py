@@ -182,3 +182,56 @@ def test_device_builder_from_rrt_routes(gpu, O, route_wp):
         np.testing.assert_allclose(ff[b], f, rtol=1e-11, atol=1e-9)
         assert abs(caug[b] - c) <= 1e-11 * abs(c)
     slv.close()
+
+
+def test_problem_create_from_weights(gpu, O, route_wp):
+    """Row f2, family half (main_FANUC.m:64-127, RRTstar_CFS.m:124-187, main_2L.m:69-121): the library assembles QQ, Qaug,
+    alpha and the state-cost terms from (robot, H, Qp, Qv, Rblk, cR); neither QQ nor Qaug crosses the boundary."""
+    import copy
+    import time
+    for name, (R, s, obs) in (("main_FANUC", gpu.main_FANUC_problem()), ("RRTstar_CFS", gpu.RRTstar_CFS_problem(route_wp)),
+                              ("main_2L", gpu.main_2L_problem(lim=(1, 1)))):
+        s0 = copy.copy(s)
+        s0.alpha = 0.0                                           # ask the library for 1/max(svd(QQ)) (main_FANUC.m:120)
+        t0 = time.perf_counter()
+        slv = gpu.CFSBatch(s0, len(obs), [o["D"] for o in obs], mode="PSGCFS", max_batch=4, use_weights=True)
+        t_create = time.perf_counter() - t0
+        QQ, alpha = slv.family()
+        scale = np.abs(s.QQ).max()
+        assert np.abs(QQ - s.QQ).max() <= 1e-13 * scale, (name, np.abs(QQ - s.QQ).max() / scale)
+        assert abs(alpha - s.alpha) <= 1e-12 * s.alpha, (name, alpha, s.alpha)
+        print(f"[from_weights] {name}: nn = {s.H * s.nu}, create {t_create * 1e3:.0f} ms, max|QQ - driver's QQ| / max|QQ| = "
+              f"{np.abs(QQ - s.QQ).max() / scale:.1e}, alpha rel diff {abs(alpha - s.alpha) / s.alpha:.1e}")
+        if s.nu == 5:                                            # device builder works at once: no cfs_set_state_cost call
+            dev = torch.device("cuda:0")
+            x0 = torch.tensor(s.xR[:5, 0][None], dtype=torch.float64, device=dev).contiguous()
+            xg = torch.tensor(s.x_.reshape(s.H, 10)[-1, :5][None], dtype=torch.float64, device=dev).contiguous()
+            _, xR1, ff, caug = slv.build_terms_device(x0, xg)
+            torch.cuda.synchronize()
+            from motionplanning_5d_m_amd.sysinfo import cost_terms
+            f, c = cost_terms(s.Aaug, s.Baug, s.Qaug_state, s.xR[:, 0], s.x_.reshape(s.H, 10)[-1, :5], s.H, 5)
+            np.testing.assert_allclose(ff.cpu().numpy()[0], f, rtol=1e-11, atol=1e-8)
+            assert abs(caug.item() - c) <= 1e-11 * abs(c)
+        slv.close()
+        # the two ways of creating the family solve alike (QQ*u goes through Baug and the 2nj x 2nj blocks in one, the dense
+        # matrix in the other); CFS mode for a short, non-chaotic comparison, PSGCFS costs for the structured product itself
+        for mode, cls in (("CFS", gpu.CFS_FANUC), ("PSGCFS", gpu.PSGCFS_FANUC)):
+            key = "epsilon" if mode == "CFS" else "D"
+            a = gpu.CFSBatch(s, len(obs), [o[key] for o in obs], mode=mode, max_batch=1, use_weights=True)
+            b = gpu.CFSBatch(s, len(obs), [o[key] for o in obs], mode=mode, max_batch=1, use_weights=False)
+            args = (s.x_[None], s.xR[:, 0][None], s.ff[None], np.array([s.caug]), gpu.obs_to_array(obs)[None])
+            ra, rb = a.solve(*args), b.solve(*args)
+            assert ra.status[0] == rb.status[0] and ra.iter_O[0] == rb.iter_O[0]
+            assert np.abs(ra.x_ - rb.x_).max() < 1e-8
+            n = ra.iter_O[0] - 1
+            np.testing.assert_allclose(ra.cost_all[0, :n], rb.cost_all[0, :n], rtol=1e-7)   # the two QQ differ by 1 ulp per entry; cond(H) = 7e6 at H = 40
+            a.close(); b.close()
+    # create time at the three horizons of the BASELINE configs
+    for H in (30, 40, 50):
+        R, s, obs = gpu.main_FANUC_problem()
+        sH = gpu.build_sys_info(s.robot, 5, H, s.xR[:5, 0], s.x_.reshape(30, 10)[-1, :5], np.zeros(H * 10), Qp=s.weights["Qp"], Qv=s.weights["Qv"],
+                                Rblk=s.weights["Rblk"], cR=50.0, lim=np.ones(5), max_input_blk=np.ones(5), epsilon_O=0.1, MAX_O_ITER=20)
+        t0 = time.perf_counter()
+        slv = gpu.CFSBatch(sH, 1, [0.2], mode="CFS", max_batch=1, use_weights=True)
+        print(f"[from_weights] nn = {5 * H}: cfs_problem_create_from_weights {1e3 * (time.perf_counter() - t0):.0f} ms")
+        slv.close()
