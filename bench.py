@@ -12,17 +12,28 @@ unit = one CFS outer iteration of one problem (get_con + QP + rollout + cost/sto
 section 3).  With N GPUs every rank solves its own 1024 problems (weak scaling, seed + rank) and the
 converged trajectories are all-gathered (RCCL) inside the timed region.  Rank 0 prints ONE JSON line.
 
-`roofline`: the dominant kernel is the fused solve kernel (cfs_solve_fused_kernel).  Its duration is
-measured live with HIP events recorded by the library on the launch stream over the timed steps;
-`achieved` = algorithmic bytes (585 120 B per problem-iteration at this config)
-x units per launch / that duration; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes
-committed under profiles/ (null when no such file is present).
-`cpu_baseline`: the CPU oracle (oracle/cfs_oracle.c, a restatement -- kind "port") on the host cores of
-this box, on the same 1024-problem batch (one pass), rank 0, N=1 only.
+What is timed.  W warm-up steps (exactly the number asked for), then `--blocks` (default 5) blocks of EXACTLY K steps,
+each block bracketed by barrier + torch.cuda.synchronize() on both sides; `ms_per_step` / `value` are those of the MEDIAN
+block, the spread is in `blocks`.  Steps are independent solves of the same resident batch, `--streams` of them in
+flight (one handle + HIP stream each): `value` is that throughput.  `value_single_launch` is the config-faithful figure
+of ONE batch-1024 launch with nothing else on the GPU (median of 5): units / `config.ms_single_solve_alone`.
+
+`roofline` (dominant kernel: cfs_solve_fused_kernel).  `achieved` = algorithmic bytes (585 120 B per
+problem-iteration, the dense-constraint-matrix convention) x units per launch / the kernel's average duration measured
+live with HIP events on the launch stream over the timed blocks (launches of different steps overlap, so this is a
+shared-occupancy duration); `frac_single_launch` uses the duration of one launch alone.  The kernel never forms the dense
+constraint matrix, so HBM is NOT what bounds it: `traffic` is the measured HBM bytes per launch (rocprofv3 --pmc
+FETCH_SIZE / WRITE_SIZE passes committed under profiles/, serial launches -- `traffic_source` says which file; it is not
+re-measured in this run), `hbm_actual_frac` = traffic / single-launch duration / 8 TB/s, and `valu_f64_frac` = fp64 vector
+flops per launch (same PMC source) / single-launch duration / 78.6 TFLOP/s.
+`cpu_baseline`: the CPU oracle (oracle/cfs_oracle.c, a restatement -- kind "port") on the host cores of this box, rank 0,
+N=1 only: OpenMP over a 256-problem sample of the same batch (3 warm-ups + median of 10 passes) and, under
+`single_thread`, batch-1 solves on one thread (3 warm-ups + median of 10 problems) -- BASELINE.md section 4.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -38,6 +49,7 @@ from motionplanning_5d_m_amd import parallel, workloads  # noqa: E402
 BATCH = 1024
 ALGO_BYTES_PER_UNIT = 8 * (300 + 150 + 36000 + 240 + 36000 + 150 + 300)   # SURVEY.md 8(d), config 3 = 585 120
 HBM_PEAK_GBS = 8000.0                                                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6                                                # MI355X fp64 vector peak (spec)
 
 
 def main():
@@ -45,6 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of exactly --steps steps each (median reported)")
     ap.add_argument("--mode", default="PSGCFS", choices=["CFS", "PSGCFS"],
                     help="headline solver: PSGCFS_FANUC is the solver BASELINE.json's batch-1024 config names; the other "
                          "one is measured too (shorter) and reported under 'other_mode'")
@@ -78,10 +91,12 @@ def main():
     if rank == 0 and oth is None:
         print(json.dumps(head), flush=True)
     elif rank == 0:
-        head["other_mode"] = {k: oth[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
+        head["other_mode"] = {k: oth[k] for k in ("value", "value_single_launch", "unit", "ms_per_step", "steps", "warmup", "blocks")}
         head["other_mode"]["config"] = {k: oth["config"][k] for k in ("solver", "iterations_per_step_rank0", "status_counts_rank0",
                                                                         "concurrent_solves", "ms_single_solve_alone")}
-        head["other_mode"]["roofline"] = {k: oth["roofline"][k] for k in ("achieved", "frac", "kernel_ms_per_launch", "achieved_all_streams")}
+        head["other_mode"]["roofline"] = {k: oth["roofline"][k] for k in ("achieved", "frac", "frac_single_launch", "kernel_ms_per_launch",
+                                                                            "kernel_ms_single_launch", "achieved_all_streams", "traffic",
+                                                                            "hbm_actual_frac", "valu_f64_frac")}
         print(json.dumps(head), flush=True)
     if world > 1:
         dist.barrier()
@@ -98,18 +113,29 @@ def _workload(B, rank):
     return _WL[(B, rank)]
 
 
+def _pmc(mode):
+    """(HBM bytes per launch, fp64 vector flops per launch, file) from the committed rocprofv3 PMC passes, or Nones"""
+    f = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(f):
+        return None, None, None
+    try:
+        d = json.load(open(f))
+        return d.get(f"hbm_bytes_per_launch_{mode}"), d.get(f"fp64_valu_flops_per_launch_{mode}"), "profiles/pmc_latest.json (round %s)" % d.get("round")
+    except Exception:
+        return None, None, None
+
+
 def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, headline):
     # ---- synthetic inputs (BASELINE.md section 3), generated with the GPU distance entry point, then resident in HBM
     pkg.lib().cfs_set_device(local)
     s, bt = _workload(B, rank)
     margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
     # Steps are independent solves of the same resident batch.  A single solve ends with a long tail (one
-    # workgroup per problem; the hardest problem of the batch runs ~4x longer than the average CU load), so
-    # `--streams S` keeps S solves in flight, each with its own handle (workspace) and HIP stream: the next
-    # solve's workgroups fill the CUs the previous one has already drained.
-    S = max(1, args.streams if steps >= 8 else min(args.streams, 4))   # a handful of steps cannot fill 16 queues: 4 measured best at K = 5
+    # workgroup per problem; the hardest problem of the batch is a serial chain), so `--streams S` keeps S solves in
+    # flight, each with its own handle (workspace) and HIP stream: the next solve's workgroups fill the CUs the
+    # previous one has already drained.  Handles are created from the cost weights (cfs_problem_create_from_weights).
+    S = max(1, min(args.streams, steps))
     slvs = [pkg.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=B, device=local) for _ in range(S)]
-    slv = slvs[0]
     t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()  # noqa: E731
     x_init, xR1, ff, caug, obs = t(bt.x_init), t(bt.xR1), t(bt.ff), t(bt.caug), t(bt.obs)
     noise = t(bt.noise) if mode == "PSGCFS" else None
@@ -134,29 +160,37 @@ def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, head
             dist.barrier()
         torch.cuda.synchronize()
 
-    warmup = max(warmup, S)            # every handle / stream runs at least once before the clock starts (first launches page in their scratch)
-    for i in range(warmup):
+    for i in range(warmup):            # exactly the warm-up asked for; handles beyond it take their first launch in a timed block
         step(i)
     fence()
-    # latency of one solve alone (stream 0, nothing else in flight)
-    t0 = time.perf_counter()
-    step(0)
-    fence()
-    latency_ms = (time.perf_counter() - t0) * 1e3
+    # ---- timed blocks of exactly `steps` steps ------------------------------------------------------------------------
     for sl in slvs:
         sl.profile(True)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
+    block_s = []
     fused_ms = gemm_ms = 0.0
     nsolves = 0
+    for _ in range(max(1, args.blocks)):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        fence()
+        block_s.append(time.perf_counter() - t0)
+        for sl in slvs:              # outside the timed region; the events go back to the handle's pool, so only the first
+            a, b_, n = sl.profile_read()   # block ever creates any
+            fused_ms += a; gemm_ms += b_; nsolves += n
+    # ---- one launch alone (nothing else in flight): wall latency and kernel duration, median of 5 -----------------------
+    lat_ms, lone_ms = [], []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        step(0)
+        fence()
+        lat_ms.append((time.perf_counter() - t0) * 1e3)
+        lone_ms.append(slvs[0].profile_read()[0])
     for sl in slvs:
-        a, b_, n = sl.profile_read()
-        fused_ms += a; gemm_ms += b_; nsolves += n
         sl.profile(False)
+    latency_ms, kern_lone_ms = statistics.median(lat_ms), statistics.median(lone_ms)
 
+    dt = statistics.median(block_s)
     units_step = int((out.iter_O - 1).sum().item())          # outer iterations executed in one solve of this rank
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     usum = torch.tensor([float(units_step)], dtype=torch.float64, device=dev)
@@ -170,20 +204,19 @@ def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, head
     if rank == 0:
         status = np.bincount(out.status.cpu().numpy(), minlength=4)
         kern_ms = fused_ms / max(nsolves, 1)
-        achieved = ALGO_BYTES_PER_UNIT * units_step / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(f"hbm_bytes_per_launch_{mode}")
-            except Exception:
-                traffic = None
+        algo = ALGO_BYTES_PER_UNIT * units_step
+        achieved = algo / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        achieved_lone = algo / (kern_lone_ms * 1e-3) / 1e9 if kern_lone_ms > 0 else 0.0
+        traffic, flops, src = _pmc(mode)
         res = {
             "metric": "CFS iterations/sec, 5-DoF 30-wp 8-obs batch-1024; l_inf wp err vs quadprog",
             "value": units_all * steps / dt_max,
+            "value_single_launch": units_all / (latency_ms * 1e-3),
             "unit": "CFS iterations/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt_max / steps * 1e3,
+            "blocks": {"n": len(block_s), "steps_each": steps, "ms_per_step_median": dt / steps * 1e3,
+                       "ms_per_step_min": min(block_s) / steps * 1e3, "ms_per_step_max": max(block_s) / steps * 1e3},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config3: M200i 5-DoF, H=30, 8 vertical line obstacles, batch %d per GPU, %s (%s), "
@@ -193,15 +226,25 @@ def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, head
                        "concurrent_solves": S, "ms_single_solve_alone": latency_ms,
                        "iterations_per_step_rank0": units_step,
                        "status_counts_rank0": {"converged": int(status[0]), "max_iter": int(status[1]),
-                                               "qp_infeasible": int(status[2]), "numeric": int(status[3])}},
+                                               "qp_infeasible": int(status[2]), "numeric": int(status[3])},
+                       "value_is": "throughput with %d independent solves of the batch in flight; value_single_launch is one "
+                                   "batch-1024 launch alone on the GPU" % S},
             "roofline": {"bound": "hbm", "kernel": "cfs_solve_fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms_per_launch": kern_ms, "gemm_ms_per_launch": gemm_ms / max(nsolves, 1),
+                         "frac_single_launch": achieved_lone / HBM_PEAK_GBS,
+                         "hbm_actual_frac": (traffic / (kern_lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and kern_lone_ms > 0 else None,
+                         "valu_f64_frac": (flops / (kern_lone_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if flops and kern_lone_ms > 0 else None,
+                         "traffic_source": (src + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, serial launches; "
+                                            "not re-measured in this run") if src else None,
+                         "kernel_ms_per_launch": kern_ms, "kernel_ms_single_launch": kern_lone_ms,
+                         "gemm_ms_per_launch": gemm_ms / max(nsolves, 1),
                          "algorithmic_bytes_per_unit": ALGO_BYTES_PER_UNIT, "units_per_launch": units_step,
-                         "achieved_all_streams": ALGO_BYTES_PER_UNIT * units_step * steps / dt_max / 1e9,
-                         "note": "achieved = per-launch figure (launches of different steps overlap on %d streams; "
-                                 "achieved_all_streams = bytes of all launches / wall time); true limiter is fp64 VALU + LDS "
-                                 "latency of the sequential active-set steps, not HBM (DESIGN.md)" % S},
+                         "achieved_all_streams": algo * steps / dt_max / 1e9,
+                         "note": "HBM convention of the contract (dense constraint matrix, never materialised here): `frac` is the "
+                                 "per-launch figure with %d launches sharing the chip, `frac_single_launch` one launch alone, "
+                                 "`achieved_all_streams` all launches / wall time; the kernel's actual limiter is the latency of "
+                                 "the sequential active-set steps (fp64 VALU + LDS + barriers), see hbm_actual_frac / "
+                                 "valu_f64_frac and DESIGN.md" % S},
         }
         if world == 1 and headline and not args.no_cpu_baseline:
             res["cpu_baseline"], res["accuracy"] = cpu_baseline(s, bt, mode, margin, out)
@@ -214,27 +257,62 @@ def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, head
 
 
 def cpu_baseline(s, bt, mode, margin, out):
-    """The oracle (checker, never the product path) timed on this box's host cores on the same batch."""
+    """The oracle (checker, never the product path) timed on this box's host cores: a bounded sample of the same batch."""
     from oracle import oracle as O
+    robot = O.robotproperty2("M200i")
     cores = min(O.max_threads(), os.cpu_count() or 1)
-    t0 = time.perf_counter()
-    w = O.optimizer_batch(O.robotproperty2("M200i"), mode, s.H, 5, bt.x_init, bt.xR1, s.QQ, bt.ff, bt.caug, s.Aaug, s.Baug,
-                          s.lim, s.MAX_input, bt.obs, margin, s.epsilon_O, s.MAX_O_ITER, s.alpha,
-                          noise=bt.noise if mode == "PSGCFS" else None, nthreads=cores)
-    dt = time.perf_counter() - t0
-    units = int((w.iter_O - 1).sum())
+    nz = bt.noise if mode == "PSGCFS" else None
+
+    def run(sl, threads):
+        t0 = time.perf_counter()
+        w = O.optimizer_batch(robot, mode, s.H, 5, bt.x_init[sl], bt.xR1[sl], s.QQ, bt.ff[sl], bt.caug[sl], s.Aaug, s.Baug, s.lim,
+                              s.MAX_input, bt.obs[sl], margin, s.epsilon_O, s.MAX_O_ITER, s.alpha,
+                              noise=None if nz is None else nz[sl], nthreads=threads)
+        return w, time.perf_counter() - t0
+
+    # (b) OpenMP over the batch on all host cores: 256-problem sample, 3 warm-ups + median of 10 (BASELINE.md section 4)
+    n_smp = min(256, bt.B)
+    smp = slice(0, n_smp)
+    for _ in range(3):
+        w_s, _ = run(smp, cores)
+    ts = [run(smp, cores)[1] for _ in range(10)]
+    units_s = int((w_s.iter_O - 1).sum())
+    # (a) one thread, batch 1: the like-for-like stand-in for the reference's interpreter path
+    for b in range(3):
+        run(slice(b, b + 1), 1)
+    one = [run(slice(b, b + 1), 1) for b in range(3, 13)]
+    rate1 = statistics.median([(int(w.iter_O[0]) - 1) / max(tt, 1e-9) for w, tt in one if int(w.iter_O[0]) > 1] or [0.0])
+    base = {"value": units_s / statistics.median(ts), "unit": "CFS iterations/s", "cores": cores, "kind": "port",
+            "sample": "first %d problems of the same batch (%d outer iterations per pass), OpenMP over problems, 3 warm-up passes + "
+                      "median of 10 (min %.2f s, max %.2f s)" % (n_smp, units_s, min(ts), max(ts)),
+            "single_thread": {"value": rate1, "unit": "CFS iterations/s", "cores": 1,
+                              "sample": "batch-1 solves of problems 3..12 on one thread after 3 warm-up solves, median of 10"},
+            "reference_logged": "~2 CFS iterations/s (M200i/test.xlsx row 19; unknown hardware, includes setup: non-comparable)"}
+    # accuracy of the GPU answers on the whole batch, with the problems the oracle itself cannot pin set aside
+    w, _ = run(slice(0, bt.B), cores)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import chaotic_problems
+    chaotic, _ = chaotic_problems(O, s, bt, mode, w)
     st, it, x = out.status.cpu().numpy(), out.iter_O.cpu().numpy(), out.x_.cpu().numpy()
     same = (st == w.status) & (it == w.iter_O)
     ok = same & (st < 2)
-    err = np.abs(x - w.x_).max(axis=1)[ok]
-    base = {"value": units / dt, "unit": "CFS iterations/s", "cores": cores, "kind": "port",
-            "sample": "one pass over the same %d-problem batch (%d outer iterations, %.1f s wall), OpenMP over problems" % (bt.B, units, dt)}
+    err_all = np.abs(x - w.x_).max(axis=1)
+    err, err_nc = err_all[ok], err_all[ok & ~chaotic]
     acc = {"vs": "CPU oracle (quadprog itself is closed source: parity unpinned, DESIGN.md)",
-           "status_and_iteration_agreement": float(same.mean()), "problems_compared": int(ok.sum()),
+           "status_and_iteration_agreement": float(same.mean()),
+           "status_and_iteration_agreement_non_chaotic": float(same[~chaotic].mean()),
+           "problems_compared": int(ok.sum()),
            "linf_rad_median": float(np.median(err)) if err.size else None,
            "linf_rad_p99": float(np.quantile(err, 0.99)) if err.size else None,
            "linf_rad_max": float(err.max()) if err.size else None,
-           "frac_below_1e-5_rad": float((err < 1e-5).mean()) if err.size else None}
+           "frac_below_1e-5_rad": float((err < 1e-5).mean()) if err.size else None,
+           "chaotic_definition": "the ORACLE's own answer moves by > 1e-6 rad (or changes status / iteration count) when its x_init is "
+                                 "perturbed by N(0, 1e-12^2), 3 draws",
+           "chaotic_problems": np.nonzero(chaotic)[0].tolist(),
+           "non_chaotic_compared": int((ok & ~chaotic).sum()),
+           "linf_rad_max_non_chaotic": float(err_nc.max()) if err_nc.size else None,
+           "frac_below_1e-5_rad_non_chaotic": float((err_nc < 1e-5).mean()) if err_nc.size else None,
+           "non_chaotic_misses": np.nonzero(ok & ~chaotic & (err_all >= 1e-5))[0].tolist()}
     return base, acc
 
 
