@@ -89,6 +89,21 @@ __device__ __forceinline__ double wave_add(double v)      // all lanes receive t
     return readlane_f64(v, 63);
 }
 
+// Block-wide reductions cost ONE barrier each: consecutive reductions alternate between two exchange buffers (the
+// caller passes red_a / red_b in turn), so a wavefront may still be reading the previous result while the next one is
+// being written; the buffer written two reductions ago is free because the reduction in between had a barrier.
+// Ordering of LDS traffic among the active rows.  While every active row lives in wavefront 0 (qhi <= 64: the normal
+// case, PSGCFS projections end with 2-3 active rows), writes and reads of the row vectors (d, r, rho, lambda, P
+// bookkeeping) are ordered by the wavefront's own in-order LDS queue: a wavefront-scope fence instead of s_barrier.
+__device__ __forceinline__ void sync_rows(bool one_wave)
+{
+    if (one_wave) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else __syncthreads();
+}
+
 // block-wide argmin of (v, id): every thread returns the same pair.  red: >= 2*(FT/64) doubles.
 __device__ __forceinline__ void block_argmin(double &v, int &id, double *red, int tid)
 {
@@ -97,7 +112,6 @@ __device__ __forceinline__ void block_argmin(double &v, int &id, double *red, in
     const int src = hit ? (int)__builtin_ctzll(hit) : 0;
     const int mid = __builtin_amdgcn_readlane(id, src);
     const int wv = tid >> 6;
-    __syncthreads();
     if ((tid & 63) == 0) { red[wv] = m; reinterpret_cast<int *>(red + FT / 64)[wv] = mid; }
     __syncthreads();
     double bm = red[0];
@@ -113,7 +127,6 @@ __device__ __forceinline__ void block_argmin(double &v, int &id, double *red, in
 __device__ __forceinline__ double block_sum(double v, double *red, int tid)
 {
     const double s = wave_add(v);
-    __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     double t = red[0];
@@ -126,7 +139,6 @@ __device__ __forceinline__ double block_sum(double v, double *red, int tid)
 __device__ __forceinline__ void block_sum4(double &a, double &b, double &c, double &d, double *red, int tid)
 {
     const double sa = wave_add(a), sb = wave_add(b), sc = wave_add(c), sd = wave_add(d);
-    __syncthreads();
     if ((tid & 63) == 0) { const int w = tid >> 6; red[w] = sa; red[4 + w] = sb; red[8 + w] = sc; red[12 + w] = sd; }
     __syncthreads();
     a = (red[0] + red[1]) + (red[2] + red[3]);
@@ -380,7 +392,7 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.fre = o; o += (QB + 1) / 2;          // stack of freed slots
     L.flag = o; o += (nobs * H + 4 * HN + 7) / 8;
     L.code = o; o += (nobs * H + 4 * HN + 1) / 2;
-    L.red = o; o += 32;
+    L.red = o; o += 64;                    // two exchange buffers of 24 doubles + 12 stamp accumulators
     L.small = o; o += 4 * NJ + nobs;       // lim, v0, theta0 (2NJ), margin
     L.mx = o; o += HN;                     // MAX_input
     L.cost = o; o += (int)(sizeof(DevCost) / 8);   // structure of QQ (handles created from the cost weights)
@@ -421,7 +433,9 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     unsigned char *s_flag = reinterpret_cast<unsigned char *>(lds + L.flag);
     unsigned short *s_slot = reinterpret_cast<unsigned short *>(lds + L.slot);
     int *s_code = reinterpret_cast<int *>(lds + L.code);
-    double *red = lds + L.red;
+    double *red_base = lds + L.red;
+    int red_sel = 0;
+#define red (red_base + 24 * (red_sel ^= 1))      /* every use is one block-wide reduction: alternate the buffer */
     double *s_lim = lds + L.small, *s_v0 = s_lim + NJ, *s_th0 = s_v0 + NJ, *s_margin = s_th0 + 2 * NJ;
     double *s_mx = lds + L.mx;
     double *s_pt = P.Pt + (size_t)b * P.pt_stride;        // columns [PR,QB) of P, [b-PR][a]
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         }
     }
     __syncthreads();
-    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(red + 20);   // 12 phase accumulators (developer aid)
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(red_base + 48);   // 12 phase accumulators (developer aid)
     if (tid < 12) s_acc[tid] = 0ull;
     unsigned long long t0_ = P.stamps ? clock64() : 0ull;
     double cost_new = P.caug[b], cost_old = 100000.0;      // get_cost(zeros) = caug; EVAL.m:29
@@ -772,12 +786,27 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 // thread's constraints never change, so they are decoded once per kernel -- no integer divisions here)
                 double sbest = 0.0;
                 int cbest = 0x7fffffff;
-                for (int e = tid; e < ncon; e += FT) {
+                for (int e = tid; e < nobs * H; e += FT) {      // collision rows: e = j*H + i
                     if (s_flag[e]) continue;
-                    const int code = s_code[e];
-                    double bb;
-                    const double sl = slack_of<NJ>(code, xs, s_g, s_rhs, s_lim, s_v0, s_mx, H, &bb);
-                    if (sl < -1e-11 * (1.0 + fabs(bb)) && sl < sbest) { sbest = sl; cbest = code; }
+                    const int code = s_code[e], i = (code >> 8) & 0xff;
+                    const double rh = s_rhs[e];
+                    double sl = rh;
+#pragma unroll
+                    for (int c = 0; c < NJ; ++c) sl += s_g[e * NJ + c] * xs[2 * HN + i * NJ + c];
+                    if (sl < -1e-11 * (1.0 + fabs(rh)) && sl < sbest) { sbest = sl; cbest = code; }
+                }
+                for (int k = tid; k < HN; k += FT) {            // velocity rows (and input bounds) of (waypoint, joint) k: both signs at once
+                    const int i = k / NJ, c = k - i * NJ;
+                    const double v = xs[HN + k], bp = s_lim[c] - s_v0[c], bm = s_lim[c] + s_v0[c];   // CFS_FANUC.m:127, :129
+                    const double sp_ = bp - v, sm_ = bm + v;
+                    if (!s_flag[nobs * H + k] && sp_ < -1e-11 * (1.0 + fabs(bp)) && sp_ < sbest) { sbest = sp_; cbest = mk_code(CT_VELP, i, c); }
+                    if (!s_flag[nobs * H + HN + k] && sm_ < -1e-11 * (1.0 + fabs(bm)) && sm_ < sbest) { sbest = sm_; cbest = mk_code(CT_VELM, i, c); }
+                    if (P.has_bounds) {
+                        const double bb = s_mx[k], u_ = xs[k];
+                        const double s1 = bb - u_, s2 = bb + u_;
+                        if (!s_flag[nobs * H + 2 * HN + k] && s1 < -1e-11 * (1.0 + fabs(bb)) && s1 < sbest) { sbest = s1; cbest = mk_code(CT_BNDP, i, c); }
+                        if (!s_flag[nobs * H + 3 * HN + k] && s2 < -1e-11 * (1.0 + fabs(bb)) && s2 < sbest) { sbest = s2; cbest = mk_code(CT_BNDM, i, c); }
+                    }
                 }
                 block_argmin(sbest, cbest, red, tid);
                 STAMP(2);                                   // 2: step 1 (slack scan + argmin)
@@ -816,7 +845,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         // H = I: w = n_p; d = N'n_p and n_p'n_p straight from the closed form (exactly symmetric products)
                         spp = gram_ident<NJ>(pc, pc, s_g, H, dt);
                         if (tid < qhi) s_d[tid] = myact >= 0 ? gram_ident<NJ>(myact, pc, s_g, H, dt) : 0.0;
-                        __syncthreads();
+                        sync_rows(qhi <= 64);
                         if (tid < qhi) s_r[tid] = myact >= 0 ? Pr.dot(s_d, s_pt, tid, qhi) : 0.0;
                         __syncthreads();
                     }
@@ -849,7 +878,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     STAMP(3);                               // 3: w gather + rollout
                     spp = ndot<NJ>(pc, wb, s_g, H);
                     if (tid < qhi) s_d[tid] = myact >= 0 ? ndot<NJ>(myact, wb, s_g, H) : 0.0;
-                    __syncthreads();
+                    sync_rows(qhi <= 64);
                     // r = P d
                     if (tid < qhi) s_r[tid] = myact >= 0 ? Pr.dot(s_d, s_pt, tid, qhi) : 0.0;
                     __syncthreads();
@@ -890,23 +919,22 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         const double t1w = wave_min(t1c);
                         const unsigned long long hit = __ballot(t1c == t1w);
                         const int lw = (tid & ~63) + (hit ? (int)__builtin_ctzll(hit) : 0);
-                        __syncthreads();
+                        double *rx = red;                              // one exchange buffer for this reduction (alternating)
                         if ((tid & 63) == 0) {
                             const int wv = tid >> 6;
-                            red[wv] = rr; red[4 + wv] = rmax; red[8 + wv] = dmax; red[12 + wv] = t1w;
-                            reinterpret_cast<int *>(red + 16)[wv] = lw;
+                            rx[wv] = rr; rx[4 + wv] = rmax; rx[8 + wv] = dmax; rx[12 + wv] = t1w;
+                            reinterpret_cast<int *>(rx + 16)[wv] = lw;
                         }
                         __syncthreads();
-                        rr = (red[0] + red[1]) + (red[2] + red[3]);
-                        rmax = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-                        dmax = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
-                        t1 = red[12]; l = reinterpret_cast<int *>(red + 16)[0];
+                        rr = (rx[0] + rx[1]) + (rx[2] + rx[3]);
+                        rmax = fmax(fmax(rx[4], rx[5]), fmax(rx[6], rx[7]));
+                        dmax = fmax(fmax(rx[8], rx[9]), fmax(rx[10], rx[11]));
+                        t1 = rx[12]; l = reinterpret_cast<int *>(rx + 16)[0];
 #pragma unroll
                         for (int w = 1; w < 4; ++w)
-                            if (red[12 + w] < t1) { t1 = red[12 + w]; l = reinterpret_cast<int *>(red + 16)[w]; }
+                            if (rx[12 + w] < t1) { t1 = rx[12 + w]; l = reinterpret_cast<int *>(rx + 16)[w]; }
                         const double ref = fmax(fabs(delta), DEP_TOL_F * spp);
                         if (pass == 3 || (P.opt & 2) || !(fabs(rr) > CFS_REF_A * ref || rmax > CFS_REF_B * (dmax + 1e-300))) break;
-                        __syncthreads();                               // red / s_r / s_rho are about to change
                         }
                         enter_at_correction = false;
                         if (tid < qhi) {                                // dr = P rho ; r += dr   (projection: lambda -= P s)
@@ -954,10 +982,10 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         if (slot >= QB || qhi - nfree >= nn) { qp_status = QP_NUMERIC; break; }
                         const int qn = max(qhi, slot + 1);
                         const double inv = 1.0 / delta;
-                        __syncthreads();
+                        sync_rows(qn <= 64);
                         if (tid == 0) s_r[slot] = -1.0;
-                        if (slot >= PR && slot == qhi && tid < QB) s_pt[(slot - PR) * QB + tid] = 0.0;   // fresh tail column
-                        __syncthreads();
+                        if (slot >= PR && slot == qhi && tid < QB) s_pt[(slot - PR) * QB + tid] = 0.0;   // fresh tail column: each row's own entry
+                        sync_rows(qn <= 64);
                         if (tid < qhi && myact >= 0) Pr.axpy(s_r[tid] * inv, s_r, s_pt, tid, qn);
                         else if (tid == slot) Pr.set_scaled(-inv, s_r, s_pt, tid, qn);
                         if (!IDENT) {
@@ -975,10 +1003,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     // column l up to rounding), zero row l, push the slot on the free stack
                     {
                         const int gone = s_act[l];
-                        __syncthreads();
+                        const bool one_wave = qhi <= 56;                     // the mask below covers whole 8-column chunks
+                        sync_rows(one_wave);
                         if (tid == l) Pr.store(s_prow, s_pt, tid, qhi);
-                        if (tid < QB) s_rho[tid] = tid == l ? 0.0 : 1.0;     // exact column mask
-                        __syncthreads();
+                        if (tid < QB && tid < qhi + 8) s_rho[tid] = tid == l ? 0.0 : 1.0;     // exact column mask
+                        sync_rows(one_wave);
                         const double pll = s_prow[l];
                         if (tid < qhi && myact >= 0 && tid != l) Pr.axpy_mask(-(s_prow[tid] / pll), s_prow, s_rho, s_pt, tid, qhi);
                         if (tid == l) Pr.zero(s_pt, tid, qhi);
@@ -1136,6 +1165,8 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     }
     if (P.stamps && tid == 0) for (int k = 0; k < 12; ++k) P.stamps[(size_t)b * 12 + k] = s_acc[k];
 }
+
+#undef red
 
 template <int NJ, int QB, bool IDENT>
 hipError_t launch_fused_inst2(const FusedParams &p, size_t lds, hipStream_t s)
