@@ -9,6 +9,9 @@ classdef CFS_FANUC
             if ~isempty(varargin), self.ROBOT = varargin{1}; end
             self.x_ = val2.x_; self.u = zeros(self.nn,1); self.eval = EVAL(val2);
        end
+       function self = get_con(self)                              % public Ainq / binq, reference row order (Lib/CFS_FANUC.m get_con)
+            [self.Ainq, self.binq] = cfs_mex('get_con', 0, self.obs, self.sys_info, self.ROBOT, self.x_, self.u);
+       end
        function self = optimizer(self)                            % one MEX call instead of the MATLAB loop
             [self.u, self.x_, c, ec, eu, self.iter_O, self.total_iter, self.status] = ...
                 cfs_mex('solve', 0, self.obs, self.sys_info, self.ROBOT, []);

@@ -6,6 +6,9 @@
 //        mode 0 = CFS_FANUC.optimizer (Lib/CFS_FANUC.m:62-79), 1 = PSGCFS_FANUC.optimizer (Lib/PSGCFS_FANUC.m:65-82);
 //        obs = the reference's obs cell (obs{j}.l 3x2, .epsilon, .D; obs{j}.mesh = handle for a mesh obstacle, last in the cell);
 //        noise = nn x rows matrix of normrnd(0,0.1) draws consumed one column per PSG step (PSGCFS_FANUC.m:109), or []
+//   [Ainq, binq] = cfs_mex('get_con', mode, obs, sys_info, ROBOT, x_, u)   % self.get_con() (Lib/CFS_FANUC.m:101-135): dense, reference row order
+//   [u, x_, cost_all, e_cost_all, e_u_all, iter_O] = cfs_mex('chomp', obs_, sys_info, ROBOT, uref)   % CHOMP_FANUC.optimizer (Lib/CHOMP_FANUC.m:54-69);
+//        obs_ = the reference's cell: obs_{1}.num_obs followed by the obstacles (M16iB/CHOMP.m:26-29)
 //   h = cfs_mex('mesh_load_stl', path, scale, map_from_stl)        % Lib/functions/MapFromSTL.m
 //   [dis, points] = cfs_mex('mesh_segment_distance', h, seg6)      % point2surface_dis (M200i/dist_arm_surf_200i.m:21)
 //   cfs_mex('mesh_destroy', h)
@@ -45,45 +48,60 @@ static void fill_robot(const mxArray *robot, const char *ROBOT, int nj, cfs_robo
     r.delta_t = mxGetScalar(mxGetField(robot, 0, "delta_t"));
 }
 
-static void solve(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
-{
-    if (nrhs < 5) mexErrMsgTxt("cfs_mex('solve', mode, obs, sys_info, ROBOT [, noise])");
-    const int mode = (int)mxGetScalar(prhs[1]);
-    const mxArray *obs = prhs[2], *S = prhs[3];
-    const std::string ROBOT = mxArrayToString(prhs[4]);
+// the problem-family handle of one MATLAB object: obs cell (first = index of the first obstacle in it) + sys_info + ROBOT
+struct Family {
+    cfs_problem *p = nullptr;
     cfs_problem_desc d;
+    std::vector<double> margin, obs6, Dv, epsv;
+    ~Family() { if (p) cfs_problem_destroy(p); }
+};
+static void make_family(Family &f, int mode, const mxArray *obs, int first, int nobs, const mxArray *S, const char *ROBOT)
+{
+    cfs_problem_desc &d = f.d;
     memset(&d, 0, sizeof d);
     d.mode = mode;
     d.H = (int)field_scalar(S, "H");
     d.njoint = (int)field_scalar(S, "njoint");
-    d.nobs = (int)mxGetNumberOfElements(obs);
-    fill_robot(mxGetField(S, 0, "robot"), ROBOT.c_str(), d.njoint, d.robot);
+    d.nobs = nobs;
+    fill_robot(mxGetField(S, 0, "robot"), ROBOT, d.njoint, d.robot);
     d.QQ = field_ptr(S, "QQ"); d.Aaug = field_ptr(S, "Aaug"); d.Baug = field_ptr(S, "Baug"); d.lim = field_ptr(S, "lim");
     d.MAX_input = field_ptr(S, "MAX_input", mode == CFS_MODE_CFS);
     d.epsilon_O = field_scalar(S, "epsilon_O");
     d.MAX_O_ITER = (int)field_scalar(S, "MAX_O_ITER");
     d.alpha = mxGetField(S, 0, "alpha") ? field_scalar(S, "alpha") : 0.0;
     d.max_batch = 1;
-    std::vector<double> margin(d.nobs), obs6(6 * (size_t)d.nobs, 0.0);
+    f.margin.assign(nobs, 0.0); f.obs6.assign(6 * (size_t)nobs, 0.0); f.Dv.assign(nobs, 0.0); f.epsv.assign(nobs, 0.0);
     std::vector<const cfs_mesh *> meshes;
-    for (int j = 0; j < d.nobs; ++j) {
-        const mxArray *o = mxGetCell(obs, j);
-        margin[j] = mxGetScalar(mxGetField(o, 0, mode == CFS_MODE_CFS ? "epsilon" : "D"));   // CFS_FANUC.m:117 | PSGCFS_FANUC.m:158
+    for (int j = 0; j < nobs; ++j) {
+        const mxArray *o = mxGetCell(obs, first + j);
+        f.Dv[j] = mxGetScalar(mxGetField(o, 0, "D"));
+        f.epsv[j] = mxGetScalar(mxGetField(o, 0, "epsilon"));
+        f.margin[j] = mode == CFS_MODE_CFS ? f.epsv[j] : f.Dv[j];                         // CFS_FANUC.m:117 | PSGCFS_FANUC.m:158
         const mxArray *mh = mxGetField(o, 0, "mesh");
         if (mh) meshes.push_back(mesh_of(mh));
         else if (!meshes.empty()) mexErrMsgTxt("mesh obstacles must come last in the obs cell");
-        else memcpy(&obs6[6 * (size_t)j], mxGetPr(mxGetField(o, 0, "l")), sizeof(double) * 6);   // [l(:,1); l(:,2)]
+        else memcpy(&f.obs6[6 * (size_t)j], mxGetPr(mxGetField(o, 0, "l")), sizeof(double) * 6);   // [l(:,1); l(:,2)]
     }
-    d.margin = margin.data();
-    cfs_problem *p = nullptr;
-    check(cfs_problem_create(&d, &p));
-    if (!meshes.empty()) check(cfs_problem_set_meshes(p, (int)meshes.size(), meshes.data()));
+    d.margin = f.margin.data();
+    check(cfs_problem_create(&d, &f.p));
+    if (!meshes.empty()) check(cfs_problem_set_meshes(f.p, (int)meshes.size(), meshes.data()));
+}
+
+static void solve(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
+{
+    if (nrhs < 5) mexErrMsgTxt("cfs_mex('solve', mode, obs, sys_info, ROBOT [, noise])");
+    const int mode = (int)mxGetScalar(prhs[1]);
+    const mxArray *S = prhs[3];
+    const std::string ROBOT = mxArrayToString(prhs[4]);
+    Family f;
+    make_family(f, mode, prhs[2], 0, (int)mxGetNumberOfElements(prhs[2]), S, ROBOT.c_str());
+    const cfs_problem_desc &d = f.d;
     const int nn = d.H * d.njoint, nx = d.H * 2 * d.njoint, K = d.MAX_O_ITER;
     double caug = field_scalar(S, "caug");
     cfs_batch_in in;
     memset(&in, 0, sizeof in);
     in.B = 1;
-    in.x_init = field_ptr(S, "x_"); in.xR1 = field_ptr(S, "xR"); in.ff = field_ptr(S, "ff"); in.caug = &caug; in.obs = obs6.data();
+    in.x_init = field_ptr(S, "x_"); in.xR1 = field_ptr(S, "xR"); in.ff = field_ptr(S, "ff"); in.caug = &caug; in.obs = f.obs6.data();
     if (nrhs > 5 && !mxIsEmpty(prhs[5])) { in.noise = mxGetPr(prhs[5]); in.noise_rows = (int)mxGetN(prhs[5]); }   // nn x rows, one column per draw
     mxArray *o_u = mxCreateDoubleMatrix(nn, 1, mxREAL), *o_x = mxCreateDoubleMatrix(nx, 1, mxREAL);
     mxArray *o_c = mxCreateDoubleMatrix(K, 1, mxREAL), *o_ec = mxCreateDoubleMatrix(K, 1, mxREAL), *o_eu = mxCreateDoubleMatrix(K, 1, mxREAL);
@@ -91,11 +109,51 @@ static void solve(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     cfs_batch_out out;
     out.u = mxGetPr(o_u); out.x_ = mxGetPr(o_x); out.cost_all = mxGetPr(o_c); out.e_cost_all = mxGetPr(o_ec); out.e_u_all = mxGetPr(o_eu);
     out.iter_O = &iter_O; out.total_iter = &total_iter; out.status = &status;
-    const int rc = cfs_solve_batch(p, &in, &out);
-    cfs_problem_destroy(p);
-    check(rc);
+    check(cfs_solve_batch(f.p, &in, &out));
     mxArray *outs[8] = {o_u, o_x, o_c, o_ec, o_eu, mxCreateDoubleScalar(iter_O), mxCreateDoubleScalar(total_iter), mxCreateDoubleScalar(status)};
     for (int k = 0; k < 8; ++k) { if (k < nlhs || k == 0) plhs[k] = outs[k]; else mxDestroyArray(outs[k]); }
+}
+
+// self.get_con(): dense self.Ainq / self.binq at the object's current (x_, u)  (Lib/CFS_FANUC.m:101-135, PSGCFS_FANUC.m:145-184)
+static void get_con(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
+{
+    if (nrhs < 7) mexErrMsgTxt("[Ainq, binq] = cfs_mex('get_con', mode, obs, sys_info, ROBOT, x_, u)");
+    const int mode = (int)mxGetScalar(prhs[1]);
+    const std::string ROBOT = mxArrayToString(prhs[4]);
+    Family f;
+    make_family(f, mode, prhs[2], 0, (int)mxGetNumberOfElements(prhs[2]), prhs[3], ROBOT.c_str());
+    const int nn = f.d.H * f.d.njoint, rows = f.d.nobs * f.d.H * (1 + 2 * f.d.njoint);
+    mxArray *A = mxCreateDoubleMatrix(rows, nn, mxREAL), *b = mxCreateDoubleMatrix(rows, 1, mxREAL);
+    check(cfs_get_con(f.p, 1, mxGetPr(prhs[5]), mxGetPr(prhs[6]), field_ptr(prhs[3], "xR"), f.obs6.data(), mxGetPr(A), mxGetPr(b)));
+    plhs[0] = A;
+    if (nlhs > 1) plhs[1] = b; else mxDestroyArray(b);
+}
+
+// CHOMP_FANUC(obs_, sys_info, uref, ROBOT).optimizer()  (Lib/CHOMP_FANUC.m:34-69; Lib/functions/s_Solver.m:12-21)
+static void chomp(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
+{
+    if (nrhs < 5) mexErrMsgTxt("cfs_mex('chomp', obs_, sys_info, ROBOT, uref)");
+    const mxArray *S = prhs[2];
+    const std::string ROBOT = mxArrayToString(prhs[3]);
+    const int nobs = (int)mxGetScalar(mxGetField(mxGetCell(prhs[1], 0), 0, "num_obs"));    // obs_{1}.num_obs (M16iB/CHOMP.m:26)
+    Family f;
+    make_family(f, CFS_MODE_CFS, prhs[1], 1, nobs, S, ROBOT.c_str());
+    const int nn = f.d.H * f.d.njoint, nx = f.d.H * 2 * f.d.njoint, K = f.d.MAX_O_ITER;
+    double caug = field_scalar(S, "caug");
+    cfs_batch_in in;
+    memset(&in, 0, sizeof in);
+    in.B = 1;
+    in.x_init = field_ptr(S, "x_"); in.xR1 = field_ptr(S, "xR"); in.ff = field_ptr(S, "ff"); in.caug = &caug; in.obs = f.obs6.data();
+    mxArray *o_u = mxCreateDoubleMatrix(nn, 1, mxREAL), *o_x = mxCreateDoubleMatrix(nx, 1, mxREAL);
+    mxArray *o_c = mxCreateDoubleMatrix(K, 1, mxREAL), *o_ec = mxCreateDoubleMatrix(K, 1, mxREAL), *o_eu = mxCreateDoubleMatrix(K, 1, mxREAL);
+    int iter_O = 1;
+    cfs_batch_out out;
+    memset(&out, 0, sizeof out);
+    out.u = mxGetPr(o_u); out.x_ = mxGetPr(o_x); out.cost_all = mxGetPr(o_c); out.e_cost_all = mxGetPr(o_ec); out.e_u_all = mxGetPr(o_eu);
+    out.iter_O = &iter_O;
+    check(cfs_chomp_batch(f.p, &in, mxGetPr(prhs[4]), f.Dv.data(), f.epsv.data(), &out));
+    mxArray *outs[6] = {o_u, o_x, o_c, o_ec, o_eu, mxCreateDoubleScalar(iter_O)};
+    for (int k = 0; k < 6; ++k) { if (k < nlhs || k == 0) plhs[k] = outs[k]; else mxDestroyArray(outs[k]); }
 }
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
@@ -104,6 +162,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     const std::string cmd = mxArrayToString(prhs[0]);
     if (cmd == "solve") {
         solve(nlhs, plhs, nrhs, prhs);
+    } else if (cmd == "get_con") {
+        get_con(nlhs, plhs, nrhs, prhs);
+    } else if (cmd == "chomp") {
+        chomp(nlhs, plhs, nrhs, prhs);
     } else if (cmd == "mesh_load_stl") {
         cfs_mesh *m = nullptr;
         check(cfs_mesh_load_stl(mxArrayToString(prhs[1]), nrhs > 2 ? mxGetScalar(prhs[2]) : 1.0, nrhs > 3 && mxGetScalar(prhs[3]) != 0, &m));

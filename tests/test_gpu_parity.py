@@ -192,6 +192,25 @@ def test_cfs_mode_does_not_depend_on_alpha(gpu):
             np.testing.assert_array_equal(got.total_iter, ref.total_iter)
 
 
+def test_handles_on_every_visible_device(gpu):
+    """cfs_set_device + cfs_problem_create on every visible GPU of the process, then a solve on each handle, interleaved: the
+    fused kernel's dynamic-LDS attribute is a per-device function attribute (it used to be set once per process)."""
+    R, s, obs = gpu.main_FANUC_problem()
+    n = gpu.device_count()
+    slvs = [gpu.CFSBatch(s, 1, [0.25], mode="CFS", max_batch=1, device=k) for k in range(n)]
+    args = (s.x_[None], s.xR[:, 0][None], s.ff[None], np.array([s.caug]), gpu.obs_to_array(obs)[None])
+    ref = None
+    for rep in range(2):
+        for k in range(n):
+            got = slvs[k].solve(*args)
+            assert got.status[0] == 0 and got.iter_O[0] == 11
+            ref = got if ref is None else ref
+            np.testing.assert_array_equal(got.x_, ref.x_)
+    for sl in slvs:
+        sl.close()
+    gpu.lib().cfs_set_device(0)
+
+
 def test_zero_iterations_and_max_iter_edge(gpu):
     R, s, obs = gpu.main_FANUC_problem()
     s0 = copy.copy(s); s0.MAX_O_ITER = 0

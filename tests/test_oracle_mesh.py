@@ -1,7 +1,10 @@
 """Mesh obstacles (row f3), CPU side: the brute-force oracle of the build's own point2surface_dis contract
 (parity unpinned: the reference calls the function but does not contain it) is checked against an independent
 dense-sampling estimate, analytic cases and its invariances; plus the binary-STL reader / MapFromSTL transform."""
+import os
+
 import numpy as np
+import pytest
 
 from motionplanning_5d_m_amd import mesh as M
 
@@ -100,3 +103,28 @@ def test_stl_round_trip_and_map_from_stl(tmp_path):
     np.testing.assert_allclose(w[:, 2], v[:, 1] - v[:, 1].min() - 100.0, atol=1e-12)
     big = M.assembly_line([3.15, 8.5, 0.33], n_target=10000)
     assert 8000 < big.shape[0] < 12000
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/map"), reason="the reference's STL maps exist only in the build container")
+def test_reference_stl_maps_parse_and_measure(O):
+    """Container-only (the reference cannot travel): the package's binary-STL reader takes the reference's own maps
+    (map/*.STL, Lib/functions/MapFromSTL.m:1-11) -- 27 396 / 12 620 / 2 156 triangles, SURVEY.md section 2 -- and the
+    CPU mesh oracle returns finite distances on them.  (stlread itself is an external toolbox function.)"""
+    from motionplanning_5d_m_amd import mesh as M
+    want = {"assembly line_Assem1.STL": 27396, "material_traveller.STL": 12620, "table.STL": 2156}
+    rng = np.random.default_rng(3)
+    for k, (name, nt) in enumerate(want.items()):
+        tri = M.read_stl_binary(os.path.join("/root/reference/map", name))
+        assert tri.shape == (nt, 3, 3) and np.isfinite(tri).all()
+        tri_m = M.map_from_stl(tri) / 1000.0                          # MapFromSTL.m:6-10, mm -> m
+        assert np.isfinite(tri_m).all() and tri_m.min() >= -0.1 - 1e-9       # MapFromSTL.m:8 shifts one axis by -100 mm
+        lo, hi = tri_m.reshape(-1, 3).min(axis=0), tri_m.reshape(-1, 3).max(axis=0)
+        O.mesh_register(13 + k, tri_m)
+        segs = np.concatenate([rng.uniform(lo, hi, (16, 3)), rng.uniform(lo, hi, (16, 3))], axis=1)
+        d, pts, t = O.mesh_seg_distance(13 + k, segs)
+        assert np.isfinite(d).all() and (d >= 0).all() and (t >= 0).all() and (t < nt).all()
+        on = tri_m[t]                                                  # the reported mesh point lies on the reported triangle's plane
+        nrm = np.cross(on[:, 1] - on[:, 0], on[:, 2] - on[:, 0])
+        good = np.linalg.norm(nrm, axis=1) > 1e-12
+        off = np.abs(np.einsum("ij,ij->i", nrm[good], pts[good][:, 3:] - on[good][:, 0])) / np.linalg.norm(nrm[good], axis=1)
+        assert off.max() < 1e-9

@@ -57,14 +57,30 @@ def test_rrt_trees_match_oracle_node_for_node(gpu, O, solver):
 
 @pytest.mark.gpu
 def test_parallel_rrt_then_cfs_pipeline(gpu):
-    # RRTstar_CFS.m end to end: s_Parallel_rrt -> cubic resampling to 41 points -> CFS_FANUC.optimizer()
+    """RRTstar_CFS.m end to end with its own start, goal, obstacles and weights: s_Parallel_rrt -> cubic resampling to 41
+    points -> CFS_FANUC.optimizer().  The only whole-loop numbers the reference holds are its hand-kept run logs of exactly
+    this script (M200i/test.xlsx rows 5-18 and row 19, M200i/test.csv:1; RRT is random, so they are a band, not a value):
+    final cost eval.cost_new between 1.5e5 and 4e5 (mean of 14 runs 1.964e5), iter_O - 1 between 2 and 21.  Runs whose
+    linearisation becomes infeasible have no counterpart there (the reference ignores quadprog's exitflag and would crash at
+    Lib/CFS_FANUC.m:92): they are reported, and must stay a minority."""
     pobs, s, g, region_g, region_s, off = gpu.RRTstar_problem()
-    best, iter_rrt, res = gpu.s_Parallel_rrt(pobs, s, g, region_g, region_s, off, "M200i", num_seed=6, seed=3)
-    assert not best.fail and iter_rrt >= 1 and len(res) == 6
-    assert best.route.shape[1] == min(r.route.shape[1] for r in res if not r.fail)
-    R, sys_info, obs = gpu.RRTstar_CFS_problem(best.route)
-    out = gpu.CFS_FANUC(obs, sys_info, R).optimizer()
-    assert out.status in (0, 1, 2) and out.iter_O >= 2
-    if out.status < 2:
-        x = out.x_.reshape(40, 10)
-        assert np.abs(x[:, 5:]).max() <= 1 + 1e-6
+    costs, its, infeasible = [], [], 0
+    for seed in (1, 3, 6, 9):
+        best, iter_rrt, res = gpu.s_Parallel_rrt(pobs, s, g, region_g, region_s, off, "M200i", num_seed=6, seed=seed)
+        assert not best.fail and iter_rrt >= 1 and len(res) == 6
+        assert best.route.shape[1] == min(r.route.shape[1] for r in res if not r.fail)
+        R, sys_info, obs = gpu.RRTstar_CFS_problem(best.route)
+        out = gpu.CFS_FANUC(obs, sys_info, R).optimizer()
+        assert out.status in (0, 1, 2) and out.iter_O >= 2
+        if out.status < 2:
+            x = out.x_.reshape(40, 10)
+            assert np.abs(x[:, 5:]).max() <= 1 + 1e-6
+            costs.append(out.eval.cost_new)
+            its.append(out.iter_O - 1)
+        else:
+            infeasible += 1
+    print(f"[RRT*-CFS pipeline] final costs {costs}, outer iterations {its}, infeasible linearisations {infeasible}/4 "
+          "(reference logs: 1.5e5-4e5, mean 1.964e5; 2-21 iterations)")
+    assert len(costs) >= 2
+    assert all(1.5e5 <= c <= 4e5 for c in costs), costs                 # M200i/test.xlsx col C rows 5-18
+    assert all(2 <= k <= 21 for k in its), its                           # col E minus iter_rrt = 1

@@ -17,8 +17,8 @@ route = np.load(os.path.join(ROOT, "tests", "golden", "route_wp_200i_xori.npy"))
 s, bt = workloads.config4(route, B=a.batch)
 dev = torch.device("cuda", 0)
 t = lambda x: torch.tensor(x, dtype=torch.float64, device=dev).contiguous()  # noqa: E731
-slv = pkg.CFSBatch(s, bt.nobs, bt.margin_cfs, mode="CFS", max_batch=a.batch)
-slv.set_state_cost(s.Qaug_state)
+slv = pkg.CFSBatch(s, bt.nobs, bt.margin_cfs, mode="CFS", max_batch=a.batch, use_weights=True)   # cfs_problem_create_from_weights: neither QQ nor
+                                                                                                 # Qaug crosses the boundary, the state-cost terms come with it
 rng = np.random.default_rng(20260104)
 routes = t((route[None] + 0.02 * rng.standard_normal((a.batch,) + route.shape)).transpose(0, 2, 1).copy())   # (B, nwp, 5), as config4 draws them
 obs = t(bt.obs)
