@@ -937,6 +937,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         if (pass == 3 || (P.opt & 2) || !(fabs(rr) > CFS_REF_A * ref || rmax > CFS_REF_B * (dmax + 1e-300))) break;
                         }
                         enter_at_correction = false;
+                        if (P.stamps && tid == 0 && !polish) s_acc[3] += 1000000ull;            // developer aid: refinement passes (IDENT: slot 3 is otherwise unused)
                         if (tid < qhi) {                                // dr = P rho ; r += dr   (projection: lambda -= P s)
                             const double dr = myact >= 0 ? Pr.dot(s_prow, s_pt, tid, qhi) : 0.0;
                             s_rho[tid] = dr;
