@@ -1,7 +1,7 @@
 """Developer probe: first-outer-iteration u of the fused kernel vs the oracle (config 3 and config-4 shape), plus the
 full solves; everything is saved to gpurun_out/iter1_probe.npz for offline analysis."""
 import os, sys, time, copy
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import motionplanning_5d_m_amd as pkg
 from motionplanning_5d_m_amd import workloads
@@ -36,7 +36,7 @@ s, bt = workloads.config3(lambda rb, th, ob: pkg.dist_arm(rb, th, ob)[0], B=1024
 for mode in ("CFS", "PSGCFS"):
     run("c3", s, bt, mode, 1)
     run("c3", s, bt, mode, 20)
-route = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "route_wp_200i_xori.npy"))
+route = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden", "route_wp_200i_xori.npy"))
 s4, bt4 = workloads.config4(route, B=512)
 run("c4", s4, bt4, "CFS", 1)
 run("c4", s4, bt4, "CFS", 20)

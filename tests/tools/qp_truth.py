@@ -3,7 +3,7 @@ distance function, solves the QP with the oracle, then computes the solution on 
 precision (np.longdouble Gaussian elimination of the KKT system) and compares the oracle's and the GPU's u (from
 gpurun_out/iter1_probe.npz) with it."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from types import SimpleNamespace
 from motionplanning_5d_m_amd import workloads
