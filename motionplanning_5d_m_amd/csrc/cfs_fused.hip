@@ -41,6 +41,9 @@ namespace {
 #ifndef CFS_MV_BATCH
 #define CFS_MV_BATCH 16                  // QQ*u: loads in flight per thread
 #endif
+#ifndef CFS_TU
+#define CFS_TU 8                         // tail columns of P / global rows of Y loaded per batch (independent loads in flight)
+#endif
 #ifndef CFS_PR
 #define CFS_PR 64                        // columns of each inverse-Gram row kept in registers
 #endif
@@ -266,7 +269,7 @@ __device__ __forceinline__ double gram_ident(int ca, int cp, const double *g, in
 // processed unguarded and no column is ever written through a runtime register index.
 template <int PR, int QB>
 struct PRow {
-    static constexpr int TU = 8;         // tail columns loaded per batch
+    static constexpr int TU = CFS_TU;    // tail columns loaded per batch
     double v[PR];
     __device__ __forceinline__ void zero(double *ptail, int a, int q)
     {
@@ -725,12 +728,14 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     z3 -= coef[a + 3] * s_Y[(a + 3) * HN + k];
                 }
                 for (; a < qa; ++a) z0 -= coef[a] * s_Y[a * HN + k];
-                for (a = qa; a + 8 <= qhi; a += 8) {         // rows beyond the LDS capacity: eight L2 loads in flight
-                    double t[8];
+                for (a = qa; a + CFS_TU <= qhi; a += CFS_TU) {   // rows beyond the LDS capacity: CFS_TU L2 loads in flight
+                    double t[CFS_TU];
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) t[jj] = Yg[(size_t)(a + jj) * nn + k];
-                    z0 -= coef[a] * t[0]; z1 -= coef[a + 1] * t[1]; z2 -= coef[a + 2] * t[2]; z3 -= coef[a + 3] * t[3];
-                    z0 -= coef[a + 4] * t[4]; z1 -= coef[a + 5] * t[5]; z2 -= coef[a + 6] * t[6]; z3 -= coef[a + 7] * t[7];
+                    for (int jj = 0; jj < CFS_TU; ++jj) t[jj] = Yg[(size_t)(a + jj) * nn + k];
+#pragma unroll
+                    for (int jj = 0; jj < CFS_TU; jj += 4) {
+                        z0 -= coef[a + jj] * t[jj]; z1 -= coef[a + jj + 1] * t[jj + 1]; z2 -= coef[a + jj + 2] * t[jj + 2]; z3 -= coef[a + jj + 3] * t[jj + 3];
+                    }
                 }
                 for (; a < qhi; ++a) z0 -= coef[a] * Yg[(size_t)a * nn + k];
                 zb[k] = (z0 + z1) + (z2 + z3);
