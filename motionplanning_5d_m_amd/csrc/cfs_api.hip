@@ -210,6 +210,7 @@ static double *g_dbg = nullptr;
 static int g_dbg_b = -1, g_dbg_cap = 0;
 static const int g_opt = [] { const char *e = getenv("CFS_OPT"); return e ? atoi(e) : 0; }();   // developer A/B switches, read once
 static const double g_polish_tol = [] { const char *e = getenv("CFS_POLISH_TOL"); return e ? atof(e) : 1e-11; }();   // = the scan's feasibility tolerance
+static const int g_warm_max = [] { const char *e = getenv("CFS_WARM_MAX"); return e ? atoi(e) : 0; }();
 static int g_no_prune = 0;       // cfs_debug_no_prune: linearise without candidate pruning (test of the pruning's bit-exactness)
 
 int cfs_fail(int code, const char *fmt, ...)
@@ -600,6 +601,7 @@ static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
     fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(p->nn);
     fp.opt = g_opt;
     fp.polish_tol = g_polish_tol;
+    fp.warm_max = g_warm_max;
 }
 
 int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream)

@@ -108,6 +108,7 @@ struct FusedParams {
     double *st_cost;             // B x 2       cost_new, cost_old
     int *st_noise, *st_done;     // B           noise rows consumed; 1 when the problem has finished
     // pieces of the path through the SAME kernel (cfs_linearize / cfs_get_con / cfs_qp, kernel-level parity tests):
+    int warm_max;                // developer knob: largest previous active set (slots) the warm start takes (0: the register-resident columns)
     int piece;                   // 0: whole solve; 1: linearise x_init and return (dump_*); 2: one QP on the given linearisation
                                  //    (ext_dist / ext_grad with nmesh = nobs, u = linearisation point in, solution out, x0 = start)
     int no_prune;                // test switch: evaluate every link at every evaluation point of num_jac (no candidate pruning)

@@ -376,7 +376,7 @@ struct PRow {
 };
 
 struct FusedLayout {      // LDS offsets in doubles, computed identically on host and device
-    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, flag, slot, code, red, small, mx, cost, ptail, lin, y, total_fixed;
+    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, prev, flag, slot, code, red, small, mx, cost, ptail, lin, y, total_fixed;
 };
 __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int QB, int PR)
 {
@@ -393,6 +393,7 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.xs = o; o += 3 * HN;
     L.act = o; o += (QB + 1) / 2;
     L.fre = o; o += (QB + 1) / 2;          // stack of freed slots
+    L.prev = o; o += (QB + 1) / 2;         // active rows (codes per slot) at the end of the previous QP: the warm start
     L.flag = o; o += (nobs * H + 4 * HN + 7) / 8;
     L.code = o; o += (nobs * H + 4 * HN + 1) / 2;
     L.red = o; o += 64;                    // two exchange buffers of 24 doubles + 12 stamp accumulators
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     double *s_d = lds + L.d, *s_r = lds + L.r, *s_rho = lds + L.rho, *s_lam = lds + L.lam, *s_prow = lds + L.prow;
     int *s_act = reinterpret_cast<int *>(lds + L.act);
     int *s_free = reinterpret_cast<int *>(lds + L.fre);
+    int *s_prev = reinterpret_cast<int *>(lds + L.prev);
     unsigned char *s_flag = reinterpret_cast<unsigned char *>(lds + L.flag);
     unsigned short *s_slot = reinterpret_cast<unsigned short *>(lds + L.slot);
     int *s_code = reinterpret_cast<int *>(lds + L.code);
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     }
 
     PRow<PR, QB> Pr;                                       // row `tid` of P = (N'H^{-1}N)^{-1}
+    int prev_q = 0;                                        // slots [0, prev_q) of s_prev hold the previous QP's final active rows
 
     while (!done) {
         // =========================================================================================
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             for (int k = tid; k < HN; k += FT) wb[k] = s_u[k];
             for (int e = tid; e < ncon; e += FT) { s_flag[e] = 0; s_slot[e] = 0; }
             Pr.zero(s_pt, tid, 0);
-            if (tid < QB) { s_d[tid] = 0.0; s_r[tid] = 0.0; s_rho[tid] = 0.0; s_prow[tid] = 0.0; s_lam[tid] = 0.0; s_act[tid] = -1; }
+            if (tid < QB) { s_prev[tid] = s_act[tid]; s_d[tid] = 0.0; s_r[tid] = 0.0; s_rho[tid] = 0.0; s_prow[tid] = 0.0; s_lam[tid] = 0.0; s_act[tid] = -1; }
             __syncthreads();
             roll_lds<NJ>(wb, H, dt, tid);
             roll_lds<NJ>(xs, H, dt, tid);
@@ -785,6 +788,100 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 fbound = 1.0001 * 0.5 * fmin(lmax * ru * ru, P.lmax_vel * rs * rs);
             }
             STAMP(1);                                       // 1: QP setup
+            // ---- warm start (H = I): begin at the S-pair of the previous outer iteration's active rows ------------------------
+            // Consecutive outer iterations linearise nearly the same trajectory, so the optimal active set barely changes (the
+            // long problems of config 3: 8-12 rows, 80-100 % kept), yet a cold dual active set re-adds every row one full step
+            // at a time.  Goldfarb-Idnani may start from ANY S-pair (x minimises over the equality-constrained rows A, their
+            // multipliers are >= 0): build P for the previous rows -- Gram products only, wavefront 0 alone, no scan, no combine,
+            // no block barrier --, take lambda = -P s(x0), drop rows with lambda <= 0 until none is left, set x = x0 + N lambda.
+            // The optimum is the same (strictly convex QP); what changes is the number of steps.
+            if (IDENT && P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= (P.warm_max > 0 ? P.warm_max : PR)) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps
+                int *pub = reinterpret_cast<int *>(red_base + 62);
+                if (tid < 64) {
+                    int q = 0;
+                    for (int s0 = 0; s0 < prev_q; ++s0) {
+                        const int c = s_prev[s0];
+                        if (c < 0) continue;
+                        const int mine = tid < q ? s_act[tid] : -1;
+                        const double dv = mine >= 0 ? gram_ident<NJ>(mine, c, s_g, H, dt) : 0.0;
+                        s_d[tid] = dv;
+                        const double spp_ = gram_ident<NJ>(c, c, s_g, H, dt);
+                        sync_rows(true);
+                        const double rv = mine >= 0 ? Pr.dot(s_d, s_pt, tid, q) : 0.0;
+                        const double delta_ = spp_ - wave_add(dv * rv);
+                        if (!(delta_ > 1e-6 * spp_)) { sync_rows(true); continue; }   // (nearly) dependent on the rows taken so far: left to the main loop
+                        const int slot = q, qn = q + 1;
+                        const double inv = 1.0 / delta_;
+                        s_r[tid] = tid == slot ? -1.0 : rv;
+                        if (slot >= PR) s_pt[(slot - PR) * QB + tid] = 0.0;            // fresh tail column, this wavefront's rows
+                        sync_rows(true);
+                        if (tid < q) Pr.axpy(rv * inv, s_r, s_pt, tid, qn);
+                        else if (tid == slot) Pr.set_scaled(-inv, s_r, s_pt, tid, qn);
+                        if (tid == 0) {
+                            const int ct = c >> 16, ci = (c >> 8) & 0xff, cj = c & 0xff;
+                            const int cidx = ct == CT_COL ? cj * H + ci : nobs * H + (ct - 1) * HN + ci * NJ + cj;
+                            s_act[slot] = c; s_flag[cidx] = 1; s_slot[cidx] = (unsigned short)(slot + 1);
+                        }
+                        q = qn;
+                        sync_rows(true);
+                    }
+                    int nf = 0;
+                    double lamv = 0.0, s0v = 0.0;
+                    bool ok = true;
+                    for (int round = 0;; ++round) {
+                        const int mine = tid < q ? s_act[tid] : -1;
+                        double bb;
+                        s0v = mine >= 0 ? slack_of<NJ>(mine, xs, s_g, s_rhs, s_lim, s_v0, s_mx, H, &bb) : 0.0;
+                        s_d[tid] = s0v;
+                        sync_rows(true);
+                        lamv = mine >= 0 ? -Pr.dot(s_d, s_pt, tid, q) : 0.0;
+                        const double mn = wave_min(mine >= 0 ? lamv : INFINITY);
+                        if (!(mn <= 0.0)) break;                                       // every multiplier positive (or no row left)
+                        if (round == 12) { ok = false; break; }
+                        const unsigned long long hit = __ballot(mine >= 0 && lamv == mn);
+                        const int l = (int)__builtin_ctzll(hit);
+                        sync_rows(true);
+                        if (tid == l) Pr.store(s_prow, s_pt, tid, q);
+                        s_rho[tid] = tid == l ? 0.0 : 1.0;
+                        sync_rows(true);
+                        const double pll = s_prow[l];
+                        if (mine >= 0 && tid != l) Pr.axpy_mask(-(s_prow[tid] / pll), s_prow, s_rho, s_pt, tid, q);
+                        if (tid == l) Pr.zero(s_pt, tid, q);
+                        if (tid == 0) {
+                            const int gone = s_act[l], gt = gone >> 16, gi = (gone >> 8) & 0xff, gj = gone & 0xff;
+                            const int gidx = gt == CT_COL ? gj * H + gi : nobs * H + (gt - 1) * HN + gi * NJ + gj;
+                            s_act[l] = -1; s_free[nf] = l; s_flag[gidx] = 0; s_slot[gidx] = 0;
+                        }
+                        ++nf;
+                        sync_rows(true);
+                    }
+                    if (!ok) {                                                         // give up: cold start
+                        const int mine = tid < q ? s_act[tid] : -1;
+                        if (mine >= 0) {
+                            const int gt = mine >> 16, gi = (mine >> 8) & 0xff, gj = mine & 0xff;
+                            const int gidx = gt == CT_COL ? gj * H + gi : nobs * H + (gt - 1) * HN + gi * NJ + gj;
+                            s_flag[gidx] = 0; s_slot[gidx] = 0; s_act[tid] = -1;
+                        }
+                        Pr.zero(s_pt, tid, 0);
+                        q = 0; nf = 0; lamv = 0.0;
+                    }
+                    const int mine = tid < q ? s_act[tid] : -1;
+                    s_lam[tid] = mine >= 0 ? lamv : 0.0;
+                    s_r[tid] = mine >= 0 ? -lamv : 0.0;                                // combine below: zb = x0 - N(-lambda)
+                    const double fg = -0.5 * wave_add(mine >= 0 ? lamv * s0v : 0.0);  // f(x) - f(x0) = 1/2 lambda'G lambda = -1/2 lambda's(x0)
+                    if (tid == 0) { pub[0] = q; pub[1] = nf; red_base[61] = fg; }
+                }
+                __syncthreads();
+                qhi = pub[0]; nfree = pub[1]; fgain = red_base[61];
+                iters = qhi - nfree;
+                if (qhi > nfree) {
+                    n_combine(s_r, xs, 0);
+                    __syncthreads();
+                    for (int k = tid; k < 3 * HN; k += FT) xs[k] = zb[k];
+                    __syncthreads();
+                }
+            }
+            STAMP(3);                                       // 3: warm start (H = I) | w gather + rollout (H = QQ, inside the steps)
             for (;;) {
                 if (fgain > fbound) { qp_status = QP_INFEASIBLE; break; }
                 // step 1: most violated constraint (constraints are strided over the threads; the codes of a
@@ -942,7 +1039,6 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         if (pass == 3 || (P.opt & 2) || !(fabs(rr) > CFS_REF_A * ref || rmax > CFS_REF_B * (dmax + 1e-300))) break;
                         }
                         enter_at_correction = false;
-                        if (P.stamps && tid == 0 && !polish) s_acc[3] += 1000000ull;            // developer aid: refinement passes (IDENT: slot 3 is otherwise unused)
                         if (tid < qhi) {                                // dr = P rho ; r += dr   (projection: lambda -= P s)
                             const double dr = myact >= 0 ? Pr.dot(s_prow, s_pt, tid, qhi) : 0.0;
                             s_rho[tid] = dr;
@@ -1036,6 +1132,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             }
         }
         total_iter += iters;
+        if (!skip) prev_q = qp_status == QP_OK ? qhi : 0;
         if (P.dump_lambda) {
             const int nlam = nobs * H + 4 * HN;
             __syncthreads();
