@@ -179,7 +179,18 @@ __device__ __forceinline__ double half_scan_incl(double v)
 template <int NJ>
 __device__ __forceinline__ void roll_lds(double *buf, int H, double dt, int tid)
 {
-    const int HN = H * NJ, lane = tid & 63, wv = tid >> 6;
+    const int HN = H * NJ;
+    if (H <= 32) {                              // two joints per wavefront, one per half: all NJ <= 6 joints in one round of 3 wavefronts
+        const int lane = tid & 31;
+        for (int c = tid >> 5; c < NJ; c += 2 * (FT / 64)) {
+            const double x = lane < H ? buf[lane * NJ + c] : 0.0;
+            const double sv = dt * half_scan_incl(x);
+            const double sp = dt * half_scan_incl(sv) - (0.5 * dt) * sv;
+            if (lane < H) { buf[HN + lane * NJ + c] = sv; buf[2 * HN + lane * NJ + c] = sp; }
+        }
+        return;
+    }
+    const int lane = tid & 63, wv = tid >> 6;
     for (int c = wv; c < NJ; c += FT / 64) {
         const double x = lane < H ? buf[lane * NJ + c] : 0.0;
         const double sv = dt * wave_scan_incl(x);
