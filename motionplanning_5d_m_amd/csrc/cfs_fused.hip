@@ -755,6 +755,30 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 zb[k] = (z0 + z1) + (z2 + z3);
             }
         };
+        // the same with the rollouts (Bvel z, Bpos z) fused in: thread = (waypoint, joint), two joints per wavefront, scans in
+        // registers -- one barrier less per pass.  Only while every Y row is in LDS (the strided mapping would uncoalesce Yg).
+        auto y_combine_roll = [&](const double *coef, const double *base) {
+            const int lane = tid & 31;
+            for (int c = tid >> 5; c < NJ; c += 2 * (FT / 64)) {
+                const int k = lane * NJ + c;
+                double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+                if (lane < H) {
+                    z0 = base ? base[k] : 0.0;
+                    int a = 0;
+                    for (; a + 4 <= qhi; a += 4) {
+                        z0 -= coef[a] * s_Y[a * HN + k];
+                        z1 -= coef[a + 1] * s_Y[(a + 1) * HN + k];
+                        z2 -= coef[a + 2] * s_Y[(a + 2) * HN + k];
+                        z3 -= coef[a + 3] * s_Y[(a + 3) * HN + k];
+                    }
+                    for (; a < qhi; ++a) z0 -= coef[a] * s_Y[a * HN + k];
+                }
+                const double z = (z0 + z1) + (z2 + z3);
+                const double sv = dt * half_scan_incl(z);
+                const double spo = dt * half_scan_incl(sv) - (0.5 * dt) * sv;
+                if (lane < H) { zb[k] = z; zb[HN + k] = sv; zb[2 * HN + k] = spo; }
+            }
+        };
         if (!skip) {
             // rhs = (d - margin) - Diff'*Bj(1:nj,:)*u   (CFS_FANUC.m:119-120), with Bpos*u from a rollout of u
             for (int k = tid; k < HN; k += FT) wb[k] = s_u[k];
@@ -1005,6 +1029,9 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         if (!enter_at_correction) {
                         if (IDENT) {
                             n_combine(pass == 0 ? s_r : s_rho, pass == 0 ? nullptr : zb, pc);
+                            __syncthreads();
+                        } else if (H <= 32 && qhi <= QY) {
+                            y_combine_roll(pass == 0 ? s_r : s_rho, pass == 0 ? wb : zb);
                             __syncthreads();
                         } else {
                         y_combine(pass == 0 ? s_r : s_rho, pass == 0 ? wb : zb);       // pass>0: correction dr held in s_rho
