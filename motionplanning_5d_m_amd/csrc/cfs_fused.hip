@@ -779,6 +779,32 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 if (lane < H) { zb[k] = z; zb[HN + k] = sv; zb[2 * HN + k] = spo; }
             }
         };
+        // wb = (w, Bvel w, Bpos w) for w = H^{-1} n_code (H = QQ): a gather of <= NJ columns of the family matrices and of their
+        // precomputed rollouts -- no prefix sums; the caller puts a barrier behind it
+        auto gather_w = [&](int code) {
+            const int ptype_ = code >> 16, pi_ = (code >> 8) & 0xff, pj_ = code & 0xff;
+            for (int k = tid; k < HN; k += FT) {
+                double w0, w1, w2;
+                if (ptype_ == CT_COL) {
+                    w0 = w1 = w2 = 0.0;
+#pragma unroll
+                    for (int cs = 0; cs < NJ; ++cs) {
+                        const double gc = s_g[(pj_ * H + pi_) * NJ + cs];
+                        const size_t o = (size_t)(pi_ * NJ + cs) * nn + k;
+                        w0 += gc * P.M1[o];
+                        if (!(P.opt & 1)) { w1 += gc * P.M1v[o]; w2 += gc * P.M1p[o]; }
+                    }
+                } else {
+                    const bool vel = ptype_ == CT_VELP || ptype_ == CT_VELM;
+                    const double sg = (ptype_ == CT_VELP || ptype_ == CT_BNDP) ? -1.0 : 1.0;
+                    const size_t o = (size_t)(pi_ * NJ + pj_) * nn + k;
+                    w0 = sg * (vel ? P.M2 : P.M3)[o];
+                    w1 = w2 = 0.0;
+                    if (!(P.opt & 1)) { w1 = sg * (vel ? P.M2v : P.M3v)[o]; w2 = sg * (vel ? P.M2p : P.M3p)[o]; }
+                }
+                wb[k] = w0; wb[HN + k] = w1; wb[2 * HN + k] = w2;
+            }
+        };
         if (!skip) {
             // rhs = (d - margin) - Diff'*Bj(1:nj,:)*u   (CFS_FANUC.m:119-120), with Bpos*u from a rollout of u
             for (int k = tid; k < HN; k += FT) wb[k] = s_u[k];
@@ -830,17 +856,27 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // multipliers are >= 0): build P for the previous rows -- Gram products only, wavefront 0 alone, no scan, no combine,
             // no block barrier --, take lambda = -P s(x0), drop rows with lambda <= 0 until none is left, set x = x0 + N lambda.
             // The optimum is the same (strictly convex QP); what changes is the number of steps.
-            if (IDENT && P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= (P.warm_max > 0 ? P.warm_max : PR)) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps
+            if (P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= (P.warm_max > 0 ? P.warm_max : PR) && (IDENT || prev_q <= QY)) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps
                 int *pub = reinterpret_cast<int *>(red_base + 62);
+                int q = 0;                                   // H = QQ: tracked by every thread (one barrier per row); H = I: by wavefront 0
+                for (int s0 = 0; s0 < (IDENT ? 1 : prev_q); ++s0) {
+                    int c_all = -1;
+                    if (!IDENT) {                            // every thread gathers w = H^{-1} n_c; wavefront 0 decides; Y[slot] = w if taken
+                        c_all = s_prev[s0];
+                        if (c_all < 0) continue;
+                        gather_w(c_all);
+                        __syncthreads();
+                        if (P.opt & 1) { roll_lds<NJ>(wb, H, dt, tid); __syncthreads(); }
+                    }
                 if (tid < 64) {
-                    int q = 0;
-                    for (int s0 = 0; s0 < prev_q; ++s0) {
-                        const int c = s_prev[s0];
+                    for (int s1 = IDENT ? 0 : s0; s1 < (IDENT ? prev_q : s0 + 1); ++s1) {
+                        const int c = s_prev[s1];
                         if (c < 0) continue;
                         const int mine = tid < q ? s_act[tid] : -1;
-                        const double dv = mine >= 0 ? gram_ident<NJ>(mine, c, s_g, H, dt) : 0.0;
+                        const double dv = mine >= 0 ? (IDENT ? gram_ident<NJ>(mine, c, s_g, H, dt) : ndot<NJ>(mine, wb, s_g, H)) : 0.0;
                         s_d[tid] = dv;
-                        const double spp_ = gram_ident<NJ>(c, c, s_g, H, dt);
+                        const double spp_ = IDENT ? gram_ident<NJ>(c, c, s_g, H, dt) : ndot<NJ>(c, wb, s_g, H);
+                        if (!IDENT && tid == 0) pub[0] = 0;
                         sync_rows(true);
                         const double rv = mine >= 0 ? Pr.dot(s_d, s_pt, tid, q) : 0.0;
                         const double delta_ = spp_ - wave_add(dv * rv);
@@ -856,10 +892,18 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                             const int ct = c >> 16, ci = (c >> 8) & 0xff, cj = c & 0xff;
                             const int cidx = ct == CT_COL ? cj * H + ci : nobs * H + (ct - 1) * HN + ci * NJ + cj;
                             s_act[slot] = c; s_flag[cidx] = 1; s_slot[cidx] = (unsigned short)(slot + 1);
+                            if (!IDENT) pub[0] = 1;
                         }
-                        q = qn;
+                        if (IDENT) q = qn;
                         sync_rows(true);
                     }
+                }
+                    if (!IDENT) {
+                        __syncthreads();
+                        if (pub[0]) { for (int k = tid; k < HN; k += FT) s_Y[q * HN + k] = wb[k]; ++q; }   // q < QY by the entry condition
+                    }
+                }
+                if (tid < 64) {
                     int nf = 0;
                     double lamv = 0.0, s0v = 0.0;
                     bool ok = true;
@@ -910,7 +954,12 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 qhi = pub[0]; nfree = pub[1]; fgain = red_base[61];
                 iters = qhi - nfree;
                 if (qhi > nfree) {
-                    n_combine(s_r, xs, 0);
+                    if (IDENT) n_combine(s_r, xs, 0);        // zb = (x, Bvel x, Bpos x), x = x0 + N lambda
+                    else {                                   // x = x0 + Y lambda
+                        y_combine(s_r, xs);
+                        __syncthreads();
+                        roll_lds<NJ>(zb, H, dt, tid);
+                    }
                     __syncthreads();
                     for (int k = tid; k < 3 * HN; k += FT) xs[k] = zb[k];
                     __syncthreads();
@@ -987,29 +1036,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         __syncthreads();
                     }
                     if (!polish && !IDENT) {
-                    // w = H^{-1} n_p together with its rollouts (Bvel w, Bpos w): a gather of <= NJ columns of the
-                    // family matrices and of their precomputed rollouts -- no prefix sums, one barrier
-                    for (int k = tid; k < HN; k += FT) {
-                        double w0, w1, w2;
-                        if (ptype == CT_COL) {
-                            w0 = w1 = w2 = 0.0;
-#pragma unroll
-                            for (int cs = 0; cs < NJ; ++cs) {
-                                const double gc = s_g[(pj * H + pi) * NJ + cs];
-                                const size_t o = (size_t)(pi * NJ + cs) * nn + k;
-                                w0 += gc * P.M1[o];
-                                if (!(P.opt & 1)) { w1 += gc * P.M1v[o]; w2 += gc * P.M1p[o]; }
-                            }
-                        } else {
-                            const bool vel = ptype == CT_VELP || ptype == CT_VELM;
-                            const double sg = (ptype == CT_VELP || ptype == CT_BNDP) ? -1.0 : 1.0;
-                            const size_t o = (size_t)(pi * NJ + pj) * nn + k;
-                            w0 = sg * (vel ? P.M2 : P.M3)[o];
-                            w1 = w2 = 0.0;
-                            if (!(P.opt & 1)) { w1 = sg * (vel ? P.M2v : P.M3v)[o]; w2 = sg * (vel ? P.M2p : P.M3p)[o]; }
-                        }
-                        wb[k] = w0; wb[HN + k] = w1; wb[2 * HN + k] = w2;
-                    }
+                    gather_w(pc);                          // w = H^{-1} n_p with its rollouts
                     __syncthreads();
                     if (P.opt & 1) { roll_lds<NJ>(wb, H, dt, tid); __syncthreads(); }
                     STAMP(3);                               // 3: w gather + rollout
