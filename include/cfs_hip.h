@@ -167,6 +167,16 @@ int cfs_solve_batch(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out 
  * in->B <= max_batch.  This is the entry bench.py times (inputs resident in HBM). */
 int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream);
 
+/* Launch order of the fused solver: workgroup w solves problem order[w].  The added batch dimension has no counterpart in
+ * the reference; a launch lasts as long as its longest problem plus the time that problem waited for a free compute unit.
+ *   order = NULL, n = 0  automatic (default): problems whose initial trajectory violates the most (waypoint, obstacle)
+ *                        clearances first, counted by a pre-pass on the solve's stream when B > 256
+ *   order = NULL, n < 0  identity (blockIdx order)
+ *   order != NULL        HOST pointer, a permutation of 0..n-1, used by the next solves with B = n (a replanning loop may pass
+ *                        the previous solve's total_iter, sorted); synchronises the device
+ * Results do not depend on the order. */
+int cfs_set_launch_order(cfs_problem *p, const int *order, int n);
+
 /* ---- per-problem setup on the device (row f2 of the scope table) ---------------------------------------
  * replaces, for B (start, goal) pairs at once: the straight-line reference of main_FANUC.m:38-49
  * (x_ = joint-space line, zero velocities, waypoint 0 dropped), xR(:,1) = [x0; 0] and the cost terms

@@ -119,6 +119,7 @@ SYMBOLS = [
     ("cfs_problem_destroy", None, [_P]),
     ("cfs_problem_create_from_weights", C.c_int, [C.POINTER(cfs_problem_desc), C.POINTER(cfs_cost_weights), C.POINTER(_P)]),
     ("cfs_problem_family", C.c_int, [_P, _P, C.POINTER(C.c_double)]),
+    ("cfs_set_launch_order", C.c_int, [_P, _P, C.c_int]),
     ("cfs_solve_batch", C.c_int, [_P, C.POINTER(cfs_batch_in), C.POINTER(cfs_batch_out)]),
     ("cfs_solve_batch_device", C.c_int, [_P, C.POINTER(cfs_batch_in), C.POINTER(cfs_batch_out), _P]),
     ("cfs_set_state_cost", C.c_int, [_P, _P]),

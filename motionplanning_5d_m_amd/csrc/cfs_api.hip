@@ -178,6 +178,8 @@ struct cfs_problem {
     // workspace (max_batch problems)
     DevBuf<double> x0, qu, dist, grad, Yg, Pt, u_hist, qu_hist;
     DevBuf<int> noise_row, linkid;
+    DevBuf<int> order, okey;   // launch order of the fused solver: automatic (violation count of the initial trajectory), given, or identity
+    int order_mode = 0, order_n = 0;   // 0 automatic, 1 given (order_n entries), 2 identity
     // mesh obstacles (cfs_problem_set_meshes): the last nmesh of the nobs obstacles
     int nmesh = 0;
     DevBuf<DevMesh> meshes_d;
@@ -196,7 +198,7 @@ struct cfs_problem {
         for (auto &m : Mr) m.release();
         F1.release(); F2.release(); Cq.release(); cost.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
-        grad.release(); Yg.release(); noise_row.release();
+        grad.release(); Yg.release(); noise_row.release(); order.release(); okey.release();
         linkid.release(); meshes_d.release(); st_cost.release(); st_done.release();
         m_ends.release(); m_base.release(); m_shift.release(); m_tri.release(); m_near.release(); m_upper.release();
         m_pd.release(); m_pnd.release(); m_pi.release();
@@ -208,9 +210,13 @@ static unsigned long long *g_stamps = nullptr;
 static int g_stamps_B = 0;
 static double *g_dbg = nullptr;
 static int g_dbg_b = -1, g_dbg_cap = 0;
-static const int g_opt = [] { const char *e = getenv("CFS_OPT"); return e ? atoi(e) : 0; }();   // developer A/B switches, read once
-static const double g_polish_tol = [] { const char *e = getenv("CFS_POLISH_TOL"); return e ? atof(e) : 1e-11; }();   // = the scan's feasibility tolerance
-static const int g_warm_max = [] { const char *e = getenv("CFS_WARM_MAX"); return e ? atoi(e) : 0; }();
+// developer A/B switches, read once at load time.  (Named functions: lambdas in namespace-scope initialisers all mangle to
+// {lambda()#1} and the out-of-line copy of one was called for another.)
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static double env_double(const char *name, double dflt) { const char *e = getenv(name); return e ? atof(e) : dflt; }
+static const int g_opt = env_int("CFS_OPT", 0);
+static const double g_polish_tol = env_double("CFS_POLISH_TOL", 1e-11);   // = the scan's feasibility tolerance
+static const int g_warm_max = env_int("CFS_WARM_MAX", 0);
 static int g_no_prune = 0;       // cfs_debug_no_prune: linearise without candidate pruning (test of the pruning's bit-exactness)
 
 int cfs_fail(int code, const char *fmt, ...)
@@ -443,7 +449,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
     A_(Yg, Bm * nn * nn);
     if (desc->mode == CFS_MODE_CFS) { A_(u_hist, Bm * (size_t)desc->MAX_O_ITER * nn); A_(qu_hist, Bm * (size_t)desc->MAX_O_ITER * nn); }
-    A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H);
+    A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H); A_(order, Bm); A_(okey, Bm);
 #undef A_
 #define U_(buf, src, count) if (e == hipSuccess) e = hipMemcpy(p->buf.p, src, (count) * sizeof(*p->buf.p), hipMemcpyHostToDevice)
     U_(rb, &p->hrobot, 1); U_(QQ, desc->QQ, (size_t)nn * nn); U_(Hinv, Hinv.data(), (size_t)nn * nn);
@@ -604,6 +610,25 @@ static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
     fp.warm_max = g_warm_max;
 }
 
+static const int g_order_off = env_int("CFS_ORDER", 1) == 0;   // CFS_ORDER=0: developer A/B, no automatic order
+
+int cfs_set_launch_order(cfs_problem *p, const int *order, int n)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    if (!order) { p->order_mode = n < 0 ? 2 : 0; p->order_n = 0; return CFS_SUCCESS; }
+    if (n < 1 || n > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "n=%d outside 1..max_batch=%d", n, p->d.max_batch);
+    std::vector<char> seen((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (order[i] < 0 || order[i] >= n || seen[order[i]]) return fail(CFS_ERR_INVALID_ARG, "order is not a permutation of 0..%d (entry %d)", n - 1, i);
+        seen[order[i]] = 1;
+    }
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipDeviceSynchronize());      // a solve in flight may still be reading the previous order
+    HIPCHK(hipMemcpy(p->order.p, order, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    p->order_mode = 1; p->order_n = n;
+    return CFS_SUCCESS;
+}
+
 int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream)
 {
     if (!p || !in || !out) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
@@ -639,6 +664,19 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     fp.stamps = (g_stamps && B <= g_stamps_B) ? g_stamps : nullptr;
     fp.u_hist = (p->d.mode == CFS_MODE_CFS && K > 0) ? p->u_hist.p : nullptr;
     fp.no_prune = g_no_prune;
+    // Launch order.  Workgroups are dispatched in blockIdx order and a launch ends with its longest problem, so problems
+    // that will run long active sets should not wait for a free compute unit behind short ones.  Automatic: a pre-pass
+    // counts the clearances the initial trajectory violates (two small kernels on the same stream, ~10 us) -- only when the
+    // batch cannot start all at once anyway.
+    const int nline = p->d.nobs - p->nmesh;
+    if (p->order_mode == 1 && p->order_n == B) fp.order = p->order.p;
+    else if (p->order_mode == 0 && !g_order_off && B > 256 && nline > 0) {
+        OrderParams op;
+        op.rb = p->rb.p; op.B = B; op.H = p->d.H; op.nj = nj; op.nobs = nline; op.obs_stride = p->d.nobs;
+        op.x_init = in->x_init; op.obs = in->obs; op.margin = p->margin.p; op.key = p->okey.p; op.order = p->order.p;
+        launch_order(op, s);
+        fp.order = p->order.p;
+    }
     (void)nx;
     if (p->nmesh == 0) {
         HIPCHK(launch_fused(nj, fp, s));

@@ -47,6 +47,20 @@ struct DistArmParams {
 };
 void launch_dist_arm(const DistArmParams &p, hipStream_t s);
 
+// launch order of the fused solver (cfs_geom.hip): problems whose initial trajectory violates the most (waypoint, obstacle)
+// clearances first -- those run the longest active sets (rank correlation 0.7 with the QP steps on config 3)
+struct OrderParams {
+    const DevRobot *rb;
+    int B, H, nj, nobs;          // nobs: line obstacles only
+    int obs_stride;              // obstacles per problem in `obs` (line + mesh)
+    const double *x_init;        // B x H x 2nj
+    const double *obs;           // B x obs_stride x 6
+    const double *margin;        // obs_stride
+    int *key;                    // B
+    int *order;                  // B
+};
+void launch_order(const OrderParams &p, hipStream_t s);
+
 struct DenseConParams {
     int B, H, nj, nobs;
     double dt;
@@ -94,6 +108,7 @@ struct FusedParams {
     size_t pt_stride;
     double *dbg;                 // optional trace: 8 doubles per active-set step of problem dbg_b (developer aid)
     int dbg_b, dbg_cap;
+    const int *order;            // optional launch order: workgroup w solves problem order[w] (a permutation of 0..B-1); NULL = identity
     unsigned long long *stamps;  // optional: 16 cycle accumulators per problem (developer aid)
     int opt;                     // developer A/B switches (bit 0: gather w only and roll it on the fly)
     double *u_hist;              // CFS: B x max_o_iter x nn log of u per outer iteration (cost history computed afterwards)

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
 {
     constexpr int NS = 2 * NJ, NVT = nvt(NJ), NE = 2 * NJ + 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;   // workgroups are dispatched in blockIdx order: longest problems first when the caller knows them
     const int H = P.H, nobs = P.nobs, HN = H * NJ, nn = HN, NX = H * NS;
     const double dt = P.dt;
     constexpr int PR = QB < CFS_PR ? QB : CFS_PR;   // register-resident columns of each P row (rest: global scratch)

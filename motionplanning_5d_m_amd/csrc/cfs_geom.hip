@@ -53,6 +53,57 @@ __global__ __launch_bounds__(256) void cfs_dist_arm_kernel(DistArmParams P)
     }
 }
 
+// key[b] = number of (waypoint, line obstacle) pairs of problem b whose clearance on the initial trajectory is below the
+// margin; one workgroup per problem, one waypoint per thread
+__global__ __launch_bounds__(128) void cfs_order_key_kernel(OrderParams P)
+{
+    __shared__ __attribute__((aligned(16))) double s_rb[sizeof(DevRobot) / 8];
+    __shared__ int s_cnt;
+    {
+        const double *src = reinterpret_cast<const double *>(P.rb);
+        for (int e = threadIdx.x; e < (int)(sizeof(DevRobot) / 8); e += blockDim.x) s_rb[e] = src[e];
+    }
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const DevRobot *rb = reinterpret_cast<const DevRobot *>(s_rb);
+    const int b = blockIdx.x, ns = 2 * P.nj;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < P.H; i += blockDim.x) {
+        double ends[CFS_MAX_LINKS * 6];
+        double M[12], Mn[12];
+        for (int k = 0; k < P.nj; ++k) {
+            double sn, cs;
+            sincos(P.x_init[((size_t)b * P.H + i) * ns + k] - rb->th_off[k], &sn, &cs);
+            fk_step(rb, k, sn, cs, k == 0 ? nullptr : M, Mn);
+            for (int q = 0; q < 12; ++q) M[q] = Mn[q];
+            link_ends(rb, k, M, ends + k * 6);
+        }
+        for (int j = 0; j < P.nobs; ++j) {
+            double o6[6];
+            for (int q = 0; q < 6; ++q) o6[q] = P.obs[((size_t)b * P.obs_stride + j) * 6 + q];
+            double d = INFINITY;
+            for (int k = 0; k < P.nj; ++k) d = fmin(d, seg_seg_dist(ends + k * 6, o6));
+            cnt += d < P.margin[j];
+        }
+    }
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) P.key[b] = s_cnt;
+}
+
+// order = problems by descending key, ties by index (a stable rank: no atomics, the same order on every run)
+__global__ __launch_bounds__(256) void cfs_order_rank_kernel(OrderParams P)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ki = i < P.B ? P.key[i] : 0;
+    int rank = 0;
+    for (int j = 0; j < P.B; ++j) {          // j is uniform: scalar loads
+        const int kj = P.key[j];
+        rank += (kj > ki) || (kj == ki && j < i);
+    }
+    if (i < P.B) P.order[rank] = i;
+}
+
 // dense self.Ainq / self.binq in the reference's row order (CFS_FANUC.m:119-129), HBM-bound writer:
 // one workgroup per (problem, column), threads along the contiguous row index.
 __global__ __launch_bounds__(256) void cfs_dense_con_kernel(DenseConParams P)
@@ -106,6 +157,12 @@ void launch_dist_arm(const DistArmParams &p, hipStream_t s)
 {
     const dim3 grid((p.N + 255) / 256), block(256);
     hipLaunchKernelGGL(cfs_dist_arm_kernel, grid, block, 0, s, p);
+}
+
+void launch_order(const OrderParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(cfs_order_key_kernel, dim3(p.B), dim3(128), 0, s, p);
+    hipLaunchKernelGGL(cfs_order_rank_kernel, dim3((p.B + 255) / 256), dim3(256), 0, s, p);
 }
 
 void launch_dense_con(const DenseConParams &p, hipStream_t s)

@@ -107,6 +107,16 @@ class CFSBatch:
         self._h = h
         self._lib = lib
 
+    def set_launch_order(self, order="auto"):
+        """Workgroup w of the next solves handles problem order[w] (cfs_set_launch_order): "auto" (default: most violated
+        initial trajectories first), "identity", or a permutation of 0..B-1.  Results do not depend on it; a launch is as
+        long as its longest problem plus that problem's wait for a compute unit."""
+        if isinstance(order, str):
+            _lib.check(self._lib.cfs_set_launch_order(self._h, None, {"auto": 0, "identity": -1}[order]))
+            return
+        o = np.ascontiguousarray(order, dtype=np.int32)
+        _lib.check(self._lib.cfs_set_launch_order(self._h, _ptr(o), int(o.size)))
+
     def family(self):
         """(QQ, alpha) the handle was built with (cfs_problem_family)."""
         QQ = np.zeros((self.nn, self.nn), order="F")

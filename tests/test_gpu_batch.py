@@ -90,6 +90,33 @@ def test_batch_invariance_and_permutation(gpu, wl):
     np.testing.assert_array_equal(one.cost_all[0], full.cost_all[7])
 
 
+@pytest.mark.parametrize("mode", ["CFS", "PSGCFS"])
+def test_launch_order_does_not_change_results(gpu, wl, mode):
+    """cfs_set_launch_order: automatic (violation count of the initial trajectory, the default above 256 problems), identity
+    and a given permutation all return the same bits; a non-permutation is refused."""
+    s, bt = wl
+    n = 600                                                     # > 256: the automatic pre-pass runs
+    margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
+    noise = bt.noise[:n] if mode == "PSGCFS" else None
+    slv = gpu.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=n)
+    args = (bt.x_init[:n], bt.xR1[:n], bt.ff[:n], bt.caug[:n], bt.obs[:n])
+    auto = slv.solve(*args, noise=noise)
+    slv.set_launch_order("identity")
+    ident = slv.solve(*args, noise=noise)
+    slv.set_launch_order(np.argsort(-auto.total_iter, kind="stable"))
+    given = slv.solve(*args, noise=noise)
+    slv.set_launch_order("auto")
+    again = slv.solve(*args, noise=noise)
+    for other in (ident, given, again):
+        for k in ("u", "x_", "cost_all", "e_cost_all", "e_u_all", "iter_O", "total_iter", "status"):
+            np.testing.assert_array_equal(getattr(auto, k), getattr(other, k))
+    with pytest.raises(Exception, match="permutation"):
+        slv.set_launch_order(np.zeros(n, dtype=np.int32))
+    with pytest.raises(Exception, match="max_batch"):
+        slv.set_launch_order(np.arange(n + 1))
+    slv.close()
+
+
 def test_device_resident_entry_matches_host_entry(gpu, wl):
     s, bt = wl
     n = 96
