@@ -856,7 +856,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // multipliers are >= 0): build P for the previous rows -- Gram products only, wavefront 0 alone, no scan, no combine,
             // no block barrier --, take lambda = -P s(x0), drop rows with lambda <= 0 until none is left, set x = x0 + N lambda.
             // The optimum is the same (strictly convex QP); what changes is the number of steps.
-            if (P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= (P.warm_max > 0 ? P.warm_max : PR) && (IDENT || prev_q <= QY)) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps
+            if (P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= min(64, P.warm_max > 0 ? P.warm_max : min(PR, IDENT ? 64 : 24))) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps (measured, config 3 CFS: limit 24 -> 3.61 ms per solve, 40 -> 3.72, 64 -> 3.97)
                 int *pub = reinterpret_cast<int *>(red_base + 62);
                 int q = 0;                                   // H = QQ: tracked by every thread (one barrier per row); H = I: by wavefront 0
                 for (int s0 = 0; s0 < (IDENT ? 1 : prev_q); ++s0) {
@@ -900,7 +900,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 }
                     if (!IDENT) {
                         __syncthreads();
-                        if (pub[0]) { for (int k = tid; k < HN; k += FT) s_Y[q * HN + k] = wb[k]; ++q; }   // q < QY by the entry condition
+                        if (pub[0]) {
+                            if (q < QY) { for (int k = tid; k < HN; k += FT) s_Y[q * HN + k] = wb[k]; }
+                            else { for (int k = tid; k < HN; k += FT) Yg[(size_t)q * nn + k] = wb[k]; }
+                            ++q;
+                        }
                     }
                 }
                 if (tid < 64) {

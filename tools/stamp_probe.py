@@ -29,3 +29,6 @@ worst = np.argsort(-tot)[:5]
 print("slowest problems:", [(int(b), int(r.status[b]), int(r.iter_O[b]), int(steps[b]), round(tot[b]*1e-5*TICK, 2)) for b in worst], "(b, status, iter_O, steps, ms)")
 print("sum of WG time / 256 CUs = %.2f ms" % (tot.sum() * 1e-5 * TICK / 256))
 np.savez(f"gpurun_out/stamps_{mode}.npz", st=st, status=r.status, iter_O=r.iter_O, steps=r.total_iter)
+for b in worst[:2]:
+    t = st[b]
+    print(f"problem {int(b)}: steps {int(steps[b])}, per step {t[2:9].sum()*TICK/100/max(steps[b],1):.2f} us: " + ", ".join(f"{n} {v*TICK/100/max(steps[b],1):.2f}" for n, v in zip(names[2:9], t[2:9])))
