@@ -609,6 +609,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     for (int ev = 1; ev < NE; ++ev) s_dv[e * NE + ev] = INFINITY;
                 }
                 __syncthreads();
+                STAMP(0);                                   // 0: base distances, candidate lists (+ the minima / differences below)
                 {
                     int offs[NJ + 1];
                     offs[0] = 0;
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     }
                 }
                 __syncthreads();
-                STAMP(11);                                  // 11: segment pairs
+                STAMP(11);                                  // 11: segment pairs of the shifted poses
                 for (int e = tid; e < Wc * nseg; e += FT) {
                     const int j = e % nseg, wi = e / nseg;
                     double dev[NE];

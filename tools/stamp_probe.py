@@ -15,7 +15,7 @@ r = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs, noise=bt.noise if mode 
 st = np.zeros((B, 12), np.uint64)
 lib.cfs_debug_stamps(B, st.ctypes.data_as(C.c_void_p))
 st = st.astype(np.float64)
-names = ["lin: minima+FD", "qp setup", "step1 scan", "w gather+roll", "d, r=Pd", "z+roll+refine", "steplen/update", "add", "drop", "post (roll,cost)", "lin: sincos+FK", "lin: segment pairs"]
+names = ["lin: base dist+minima+FD", "qp setup", "step1 scan", "w gather+roll", "d, r=Pd", "z+roll+refine", "steplen/update", "add", "drop", "post (roll,cost)", "lin: sincos+FK", "lin: shifted pairs"]
 tot = st.sum(axis=1)
 its = r.iter_O - 1; steps = r.total_iter
 TICK = 1.0 / 21.0   # s_memtime counts shader cycles here (MI355X_MICROARCH.md: tick = shader cycle, ~2.1 GHz), not the 100 MHz the
