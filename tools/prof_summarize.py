@@ -14,7 +14,7 @@ GROUPS = 7
 
 def find(d, suffix):
     g = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*" + suffix), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None      # gpurun merges into gpurun_out/: older passes may still lie there
 
 
 def counters(d):
