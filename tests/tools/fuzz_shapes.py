@@ -59,6 +59,18 @@ for case in range(ncase):
     same = got.status == want.status and got.iter_O == want.iter_O
     err = np.abs(got.x_ - want.x_).max() if same and got.status < 2 else float("nan")
     flag = "" if same and not (err > 1e-5) else "   <<<<<<"
-    bad += bool(flag)
+    if flag:            # is the ORACLE itself stable here?  kick its initial trajectory by N(0, 1e-12^2), three draws
+        import copy
+        moved = 0.0
+        for rep in range(3):
+            t2 = copy.copy(t)
+            t2.x_ = t.x_ + 1e-12 * np.random.default_rng(100 + rep).standard_normal(t.x_.shape)
+            w2 = O.optimizer(rid, t2, oobs, mode, noise=noise)
+            moved = max(moved, float("inf") if (w2.status != want.status or w2.iter_O != want.iter_O) else float(np.abs(w2.x_ - want.x_).max()))
+        chaotic = moved > 1e-6
+        flag = f"   <<<<<< oracle moves {moved:.2e} rad under a 1e-12 kick: " + ("chaotic, not counted" if chaotic else "SOLVER MISS")
+        bad += not chaotic
+    else:
+        bad += 0
     print(tag, f"-> status {got.status}/{want.status} iter {got.iter_O}/{want.iter_O} steps {got.total_iter}/{want.total_iter} linf {err:.2e}{flag}", flush=True)
 print("flagged", bad, "of", ncase)
