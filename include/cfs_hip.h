@@ -170,7 +170,7 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
 /* Launch order of the fused solver: workgroup w solves problem order[w].  The added batch dimension has no counterpart in
  * the reference; a launch lasts as long as its longest problem plus the time that problem waited for a free compute unit.
  *   order = NULL, n = 0  automatic (default): problems whose initial trajectory violates the most (waypoint, obstacle)
- *                        clearances first, counted by a pre-pass on the solve's stream when B > 256
+ *                        clearances first, counted by a pre-pass on the solve's stream when B exceeds the device's compute units
  *   order = NULL, n < 0  identity (blockIdx order)
  *   order != NULL        HOST pointer, a permutation of 0..n-1, used by the next solves with B = n (a replanning loop may pass
  *                        the previous solve's total_iter, sorted); synchronises the device

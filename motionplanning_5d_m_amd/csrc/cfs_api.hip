@@ -179,6 +179,7 @@ struct cfs_problem {
     DevBuf<double> x0, qu, dist, grad, Yg, Pt, u_hist, qu_hist;
     DevBuf<int> noise_row, linkid;
     DevBuf<int> order, okey;   // launch order of the fused solver: automatic (violation count of the initial trajectory), given, or identity
+    int n_cu = 256;            // compute units of the handle's device: a batch of at most n_cu problems starts all at once
     int order_mode = 0, order_n = 0;   // 0 automatic, 1 given (order_n entries), 2 identity
     // mesh obstacles (cfs_problem_set_meshes): the last nmesh of the nobs obstacles
     int nmesh = 0;
@@ -438,6 +439,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     p->QQ_host.assign(desc->QQ, desc->QQ + (size_t)nn * nn);
     p->d.QQ = p->d.Aaug = p->d.Baug = p->d.lim = p->d.MAX_input = p->d.margin = nullptr;
     p->device = g_device;
+    if (hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, g_device) != hipSuccess || p->n_cu < 1) p->n_cu = 256;
     p->nn = nn; p->ns = ns; p->nx = nx; p->lmax_vel = lmax_vel; p->lmax_H = lmax_H;
     build_dev_robot(desc->robot, p->hrobot);
     const size_t Bm = (size_t)desc->max_batch;
@@ -670,7 +672,7 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     // batch cannot start all at once anyway.
     const int nline = p->d.nobs - p->nmesh;
     if (p->order_mode == 1 && p->order_n == B) fp.order = p->order.p;
-    else if (p->order_mode == 0 && !g_order_off && B > 256 && nline > 0) {
+    else if (p->order_mode == 0 && !g_order_off && B > p->n_cu && nline > 0) {
         OrderParams op;
         op.rb = p->rb.p; op.B = B; op.H = p->d.H; op.nj = nj; op.nobs = nline; op.obs_stride = p->d.nobs;
         op.x_init = in->x_init; op.obs = in->obs; op.margin = p->margin.p; op.key = p->okey.p; op.order = p->order.p;
