@@ -695,6 +695,7 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
         for (int it = 0; it < std::max(K, 1); ++it) {
             lm.x_ = it == 0 ? in->x_init : out->x_;
             lm.status_done = it == 0 ? nullptr : p->st_done.p;
+            lm.seed_prev = it > 0;
             HIPCHK(launch_linearize_mesh(nj, lm, s));
             fp.resume = it > 0;
             HIPCHK(launch_fused(nj, fp, s));
@@ -1011,7 +1012,7 @@ static int linearize_piece(cfs_problem *p, int B, const PieceBuffers &pb, double
         lm.rb = p->rb.p; lm.B = B; lm.H = p->d.H; lm.nmesh = p->nmesh; lm.meshes = p->meshes_d.p;
         lm.dist = p->dist.p; lm.grad = p->grad.p;
         lm.ends = p->m_ends.p; lm.base_d = p->m_base.p; lm.upper_d = p->m_upper.p; lm.base_t = p->m_tri.p; lm.shift_d = p->m_shift.p; lm.near = p->m_near.p; lm.piece_d = p->m_pd.p; lm.piece_i = p->m_pi.p; lm.piece_nd = p->m_pnd.p;
-        lm.x_ = pb.x_; lm.status_done = nullptr;
+        lm.x_ = pb.x_; lm.status_done = nullptr; lm.seed_prev = 0;
         HIPCHK(launch_linearize_mesh(nj, lm, nullptr));
         fp.nmesh = p->nmesh; fp.ext_dist = p->dist.p; fp.ext_grad = p->grad.p;
     }

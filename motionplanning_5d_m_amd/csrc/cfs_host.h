@@ -41,6 +41,8 @@ struct LinMeshParams {           // distance + literal finite-difference Jacobia
     const DevMesh *meshes;       // device array [nmesh]
     const double *x_;            // B x (H*2*NJ)
     const int *status_done;      // B, may be null: problems whose entry is non-zero have finished and are skipped
+    int seed_prev;               // base_t holds the winning triangles of the previous outer iteration of the same problems: their
+                                 // distance to the moved link is one more upper bound (the trajectory moves little between iterations)
     double *dist;                // B x nmesh x H
     double *grad;                // B x nmesh x H x NJ
     // workspace per (problem, waypoint), sizes from linearize_mesh_workspace

@@ -465,7 +465,18 @@ __global__ __launch_bounds__(MESH_THREADS, 2) void mesh_upper_kernel(LinMeshPara
     double a6[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) a6[q] = P.ends[(((size_t)b * P.H + wp) * NVT + kvoff(k0 + 1)) * 6 + q];
-    P.upper_d[(((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm] = mesh_greedy_upper(P.meshes[jm], a6, a6 + 3);
+    const size_t o = (((size_t)b * P.H + wp) * NJ + k0) * P.nmesh + jm;
+    double up = mesh_greedy_upper(P.meshes[jm], a6, a6 + 3);
+    if (P.seed_prev) {
+        const int tp = P.base_t[o];
+        if (tp >= 0 && tp < P.meshes[jm].nt) {
+            Best bp;
+            bp.d = INFINITY; bp.t = INFINITY; bp.tri = -1;
+            seg_tri_update(a6, a6 + 3, P.meshes[jm].tri + 9 * (size_t)tp, tp, bp);
+            up = fmin(up, bp.d);
+        }
+    }
+    P.upper_d[o] = up;
 }
 
 // A link axis is queried in MESH_PIECES equal pieces: the pieces far from the surface die at the root against the common
