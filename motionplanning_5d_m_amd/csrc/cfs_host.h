@@ -25,6 +25,10 @@ struct DevMesh {                 // device view of one mesh
     const double *tri;           // nt x 9 (A, B, C), in BVH order
     const int *orig;             // BVH order -> index in the caller's triangle list
     int nnodes, nt;
+    // where a wave-cooperative traversal starts: the hierarchy cut open to <= 64 inner nodes (a wavefront's width), plus the
+    // triangles of the leaves met on the way -- the 1, 2, 4, ... lane rounds near the root are one dependent load each
+    const int *cut, *cut_tri;
+    int ncut, ncut_tri;
 };
 struct cfs_mesh {
     int device = 0, nt = 0, nnodes = 0, depth = 0;
@@ -32,7 +36,9 @@ struct cfs_mesh {
     BvhNode *nodes_d = nullptr;
     double *tri_d = nullptr;
     int *orig_d = nullptr;
-    DevMesh view() const { return DevMesh{nodes_d, tri_d, orig_d, nnodes, nt}; }
+    int *cut_d = nullptr;        // ncut node indices, then ncut_tri triangle indices
+    int ncut = 0, ncut_tri = 0;
+    DevMesh view() const { return DevMesh{nodes_d, tri_d, orig_d, nnodes, nt, cut_d, cut_d + ncut, ncut, ncut_tri}; }
 };
 
 struct LinMeshParams {           // distance + literal finite-difference Jacobian against mesh obstacles

@@ -518,8 +518,9 @@ __device__ bool mesh_query_coop(const DevMesh &m, const double *P0, const double
     for (int r = 0; r < 6; ++r) b.pts[r] = 0.0;
     near_n = 0; near_over = false;
     if (m.nt == 0) return true;
-    int nf = 1, nt = 0;
-    if (lane == 0) L.fr[0] = 0;
+    int nf = m.ncut, nt = m.ncut_tri;                           // start at the cut (<= 64 inner nodes, <= 254 triangles), not at the root
+    if (lane < nf) L.fr[lane] = m.cut[lane];
+    for (int k = lane; k < nt; k += 64) L.tr[k] = m.cut_tri[k];
     __syncthreads();
     while (nf > 0 || nt > 0) {
         if (nf > 0 && nt < 64) {
@@ -901,6 +902,22 @@ int upload_mesh(const std::vector<double> &tri9, cfs_mesh **out)
     if (e == hipSuccess) e = hipMemcpy(m->nodes_d, bd.nodes.data(), bd.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->tri_d, tri_o.data(), tri_o.size() * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->orig_d, bd.order.data(), (size_t)nt * 4, hipMemcpyHostToDevice);
+    // the cut a cooperative traversal starts from: open the hierarchy level by level while the inner nodes fit a wavefront
+    std::vector<int> cut{0}, cut_tri;
+    while (!cut.empty() && cut.size() <= 32) {
+        std::vector<int> next;
+        for (int id : cut)
+            for (int c = 0; c < 2; ++c) {
+                const int ch = bd.nodes[id].child[c];
+                if (ch >= 0) next.push_back(ch);
+                else { const int code = -(ch + 1); for (int k = 0; k < (code & 7); ++k) cut_tri.push_back((code >> 3) + k); }
+            }
+        cut.swap(next);
+    }
+    m->ncut = (int)cut.size(); m->ncut_tri = (int)cut_tri.size();
+    cut.insert(cut.end(), cut_tri.begin(), cut_tri.end());
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->cut_d), (cut.size() + 1) * 4);
+    if (e == hipSuccess && !cut.empty()) e = hipMemcpy(m->cut_d, cut.data(), cut.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         const int rc = cfs_fail(cfs_device_count() > 0 ? CFS_ERR_HIP : CFS_ERR_NO_DEVICE, "mesh upload failed: %s", hipGetErrorString(e));
         cfs_mesh_destroy(m);
@@ -1029,6 +1046,7 @@ void cfs_mesh_destroy(cfs_mesh *m)
     if (m->nodes_d) (void)hipFree(m->nodes_d);
     if (m->tri_d) (void)hipFree(m->tri_d);
     if (m->orig_d) (void)hipFree(m->orig_d);
+    if (m->cut_d) (void)hipFree(m->cut_d);
     delete m;
 }
 
