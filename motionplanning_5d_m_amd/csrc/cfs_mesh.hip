@@ -498,6 +498,8 @@ static_assert(64 + 128 * LEAF_TRIS <= CO_TR, "a round of 64 nodes can emit 128 l
 struct CoopLds {
     int fr[CO_FR];
     int tr[CO_TR];
+    double cb[128 * 6];      // boxes (lo, hi) of the children a round could not rule out cheaply, compacted
+    int cc[128];             // their child codes
     int ni[NEAR_CAP];
     float nd[NEAR_CAP];
 };
@@ -531,23 +533,57 @@ __device__ bool mesh_query_coop(const DevMesh &m, const double *P0, const double
             const bool act = lane < take;
             const int ref = act ? L.fr[nf + lane] : 0;
             __syncthreads();
-            double lc[2] = {INFINITY, INFINITY};
-            int cr[2] = {0, 0};
-            if (act) {
-                const BvhNode nd = m.nodes[ref];
-                lc[0] = node_lower_bound(P0, P1, nd.lo[0], nd.hi[0]);
-                lc[1] = node_lower_bound(P0, P1, nd.lo[1], nd.hi[1]);
-                cr[0] = nd.child[0]; cr[1] = nd.child[1];
-            }
-            const double lim = b.d + margin;
+            // Two passes.  Most children of a round are far away: the box-box distance between the segment's bounding box and
+            // the child's (a lower bound of the true distance, ~20 flops) rules them out.  What is left is compacted through
+            // LDS, so the exact segment-box bound (2-5 Newton rounds, divergent) runs once over dense lanes instead of
+            // twice over all of them.
+            const double lim = b.d + margin, lim2 = lim * lim * (1.0 + 1e-13);
+            int nc = 0;
+            {
+                BvhNode nd;
+                if (act) nd = m.nodes[ref];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const bool q = act && lc[c] <= lim;
-                const bool inner = q && cr[c] >= 0;
+                for (int c = 0; c < 2; ++c) {
+                    bool cand = false;
+                    if (act) {
+                        double g2 = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const double lo = fmin(P0[r], P1[r]), hi = fmax(P0[r], P1[r]);
+                            const double g = fmax(0.0, fmax(nd.lo[c][r] - hi, lo - nd.hi[c][r]));
+                            g2 += g * g;
+                        }
+                        cand = !(g2 * (1.0 - 1e-13) > lim2);      // an empty child has lo = +inf: g2 = inf, never a candidate
+                    }
+                    const unsigned long long mk = __ballot(cand);
+                    if (cand) {
+                        const int sl = nc + prefix_of(mk, lane);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) { L.cb[sl * 6 + r] = nd.lo[c][r]; L.cb[sl * 6 + 3 + r] = nd.hi[c][r]; }
+                        L.cc[sl] = nd.child[c];
+                    }
+                    nc += __popcll(mk);
+                }
+            }
+            __syncthreads();
+            for (int base = 0; base < nc; base += 64) {
+                const int sl = base + lane;
+                const bool has_c = sl < nc;
+                double lcx = INFINITY;
+                int chx = 0;
+                if (has_c) {
+                    double blo[3], bhi[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { blo[r] = L.cb[sl * 6 + r]; bhi[r] = L.cb[sl * 6 + 3 + r]; }
+                    lcx = node_lower_bound(P0, P1, blo, bhi);
+                    chx = L.cc[sl];
+                }
+                const bool q = has_c && lcx <= lim;
+                const bool inner = q && chx >= 0;
                 const unsigned long long mk = __ballot(inner);
-                if (inner) L.fr[nf + prefix_of(mk, lane)] = cr[c];
+                if (inner) L.fr[nf + prefix_of(mk, lane)] = chx;
                 nf += __popcll(mk);
-                const int code = -(cr[c] + 1), first = code >> 3, cnt = (q && cr[c] < 0) ? (code & 7) : 0;
+                const int code = -(chx + 1), first = code >> 3, cnt = (q && chx < 0) ? (code & 7) : 0;
 #pragma unroll
                 for (int k = 0; k < LEAF_TRIS; ++k) {
                     const bool has = k < cnt;
