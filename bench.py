@@ -37,6 +37,12 @@ import statistics
 import sys
 import time
 
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); launches that share a queue run one
+# after the other.  Independent solves are kept in flight on their own streams below, so give each its own queue (read by
+# the runtime when it initialises, i.e. before torch touches the GPU).  Measured, CFS 8 in flight: 4 queues 2.5-3.1 ms per
+# solve depending on which streams collide, 16 queues 2.05 ms.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -63,8 +69,9 @@ def main():
                          "one is measured too (shorter) and reported under 'other_mode'")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=16,
-                    help="independent solves in flight (one handle + HIP stream each); 1 = strictly serial steps")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="independent solves in flight (one handle + HIP stream each); 1 = strictly serial steps; "
+                         "0 = per solver: 2 for PSGCFS, 8 for CFS")
     ap.add_argument("--no-other-mode", action="store_true", help="measure only --mode (profiling runs)")
     args = ap.parse_args()
 
@@ -134,7 +141,12 @@ def measure(args, mode, steps, warmup, world, rank, local, dev, backend, B, head
     # workgroup per problem; the hardest problem of the batch is a serial chain), so `--streams S` keeps S solves in
     # flight, each with its own handle (workspace) and HIP stream: the next solve's workgroups fill the CUs the
     # previous one has already drained.  Handles are created from the cost weights (cfs_problem_create_from_weights).
-    S = max(1, min(args.streams, steps))
+    # How many: a launch ends with its longest chain, and the next launch fills the slots that fall idle behind it.  Measured
+    # on config 3 (ms per solve | ms per launch): PSGCFS 2 in flight 1.47 | 2.9, 3: 1.43 | 4.2, 16: 1.50 | 5.1 -- two saturate
+    # the chip and keep every launch short (6 in flight: 1.40 | 8.4); CFS (16 hardware queues) 4: 2.6, 5: 2.2, 8: 2.05, 12: 2.02,
+    # 16: 2.4 -- its 9 ms chain needs more launches behind it.
+    want = args.streams if args.streams > 0 else (2 if mode == "PSGCFS" else 8)
+    S = max(1, min(want, steps))
     slvs = [pkg.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=B, device=local) for _ in range(S)]
     t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()  # noqa: E731
     x_init, xR1, ff, caug, obs = t(bt.x_init), t(bt.xR1), t(bt.ff), t(bt.caug), t(bt.obs)
