@@ -387,7 +387,7 @@ struct PRow {
 };
 
 struct FusedLayout {      // LDS offsets in doubles, computed identically on host and device
-    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, prev, flag, slot, code, red, small, mx, cost, ptail, lin, y, total_fixed;
+    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, prev, flag, slot, code, red, small, mx, racc, cost, ptail, lin, y, total_fixed;
 };
 __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int QB, int PR)
 {
@@ -410,6 +410,7 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.red = o; o += 64;                    // two exchange buffers of 24 doubles + 12 stamp accumulators
     L.small = o; o += 4 * NJ + nobs;       // lim, v0, theta0 (2NJ), margin
     L.mx = o; o += HN;                     // MAX_input
+    L.racc = o; o += HN;                   // how far the input bounds let waypoint (i, c) move: dt^2 sum_k ((i-k)+1/2) MAX_input(k, c)
     L.cost = o; o += (int)(sizeof(DevCost) / 8);   // structure of QQ (handles created from the cost weights)
     o = (o + 1) & ~1;
     L.lin = o;                             // linearisation scratch starts here: it may overwrite the QP's work vectors below
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
 #define red (red_base + 24 * (red_sel ^= 1))      /* every use is one block-wide reduction: alternate the buffer */
     double *s_lim = lds + L.small, *s_v0 = s_lim + NJ, *s_th0 = s_v0 + NJ, *s_margin = s_th0 + 2 * NJ;
     double *s_mx = lds + L.mx;
+    double *s_racc = lds + L.racc;
     double *s_pt = P.Pt + (size_t)b * P.pt_stride;        // columns [PR,QB) of P, [b-PR][a]
     double *s_Y = lds + L.y;                        // QY rows of HN doubles; linearisation scratch in between
     const int QY = P.qy;
@@ -490,6 +492,13 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         }
     }
     __syncthreads();
+    if (P.has_bounds)
+        for (int e = tid; e < HN; e += FT) {
+            const int i = e / NJ, c = e - i * NJ;
+            double acc = 0.0;
+            for (int k = 0; k <= i; ++k) acc += ((double)(i - k) + 0.5) * s_mx[k * NJ + c];
+            s_racc[e] = (dt * dt) * acc;
+        }
     unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(red_base + 48);   // 12 phase accumulators (developer aid)
     if (tid < 12) s_acc[tid] = 0ull;
     unsigned long long t0_ = P.stamps ? clock64() : 0ull;
@@ -849,6 +858,52 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 const double ru = sqrt(p0) + sqrt(p1), rs = sqrt(p2) + sqrt(p3);
                 fbound = 1.0001 * 0.5 * fmin(lmax * ru * ru, P.lmax_vel * rs * rs);
             }
+            // Infeasibility certificate without a step (CFS_FANUC).  The velocity rows |v0 + Bvel u| <= lim (CFS_FANUC.m:126-129)
+            // confine the position offset of waypoint i to the box dt (i + 1/2) [-lim - v0, lim - v0] (trapezoid rule of the double
+            // integrator), the input bounds to +-racc.  Two collision rows of one waypoint whose normalised sum (weights 1 : w)
+            // cannot reach its right side anywhere in that box -- an arm squeezed between two obstacles -- prove the QP
+            // infeasible (Farkas, multipliers on the two rows and on box faces).  Config 3: 20-35 % of the infeasible linearisations, 10 % of all
+            // QP steps, +9 % throughput for CFS_FANUC; for PSGCFS_FANUC (opt bit 32) the test costs more than it saves (-7 %).
+            bool cert = false;
+            if ((P.has_bounds || (P.opt & 32)) && !(P.opt & 16) && nobs > 1) {      // whole solves and the QP piece (cfs_qp) alike
+                int hit = 0;
+                for (int e = tid; e < H * nobs; e += FT) {
+                    const int i = e / nobs, a = e - i * nobs;
+                    double ga[NJ], cen[NJ], rad[NJ], na2 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NJ; ++c) { ga[c] = s_g[(a * H + i) * NJ + c]; na2 += ga[c] * ga[c]; }
+                    if (!(na2 > 0.0)) continue;
+                    const double ia = 1.0 / sqrt(na2), ra = -s_rhs[a * H + i] * ia;
+#pragma unroll
+                    for (int c = 0; c < NJ; ++c) {
+                        const double f = dt * ((double)i + 0.5);
+                        double lo = f * (-s_lim[c] - s_v0[c]), hi = f * (s_lim[c] - s_v0[c]);
+                        if (P.has_bounds) { lo = fmax(lo, -s_racc[i * NJ + c]); hi = fmin(hi, s_racc[i * NJ + c]); }
+                        cen[c] = 0.5 * (lo + hi); rad[c] = fmax(0.5 * (hi - lo), 0.0);
+                    }
+                    for (int b2 = a + 1; b2 < nobs; ++b2) {
+                        double gb[NJ], nb2 = 0.0;
+#pragma unroll
+                        for (int c = 0; c < NJ; ++c) { gb[c] = s_g[(b2 * H + i) * NJ + c]; nb2 += gb[c] * gb[c]; }
+                        if (!(nb2 > 0.0)) continue;
+                        const double ib = 1.0 / sqrt(nb2), rb = -s_rhs[b2 * H + i] * ib;
+#pragma unroll
+                        for (int wk = 0; wk < 3; ++wk) {
+                            const double w = wk == 0 ? 1.0 : (wk == 1 ? 0.5 : 2.0);
+                            double lhs = 0.0, mag = 0.0;
+#pragma unroll
+                            for (int c = 0; c < NJ; ++c) {
+                                const double cc = ga[c] * ia + w * (gb[c] * ib);
+                                lhs += cc * cen[c] + fabs(cc) * rad[c];
+                                mag += fabs(cc) * (fabs(cen[c]) + rad[c]);
+                            }
+                            const double rhs_ = ra + w * rb;
+                            if (lhs < rhs_ - 1e-9 * (1.0 + fabs(rhs_) + mag)) hit = 1;
+                        }
+                    }
+                }
+                cert = block_sum((double)hit, red, tid) > 0.0;     // (no __syncthreads_or: it would add static LDS to a kernel sized to the byte)
+            }
             STAMP(1);                                       // 1: QP setup
             // ---- warm start (H = I): begin at the S-pair of the previous outer iteration's active rows ------------------------
             // Consecutive outer iterations linearise nearly the same trajectory, so the optimal active set barely changes (the
@@ -857,7 +912,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // multipliers are >= 0): build P for the previous rows -- Gram products only, wavefront 0 alone, no scan, no combine,
             // no block barrier --, take lambda = -P s(x0), drop rows with lambda <= 0 until none is left, set x = x0 + N lambda.
             // The optimum is the same (strictly convex QP); what changes is the number of steps.
-            if (P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= min(64, P.warm_max > 0 ? P.warm_max : min(PR, IDENT ? 64 : 24))) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps (measured, config 3 CFS: limit 24 -> 3.61 ms per solve, 40 -> 3.72, 64 -> 3.97)
+            if (P.piece == 0 && !cert && !(P.opt & 8) && prev_q > 0 && prev_q <= min(64, P.warm_max > 0 ? P.warm_max : min(PR, IDENT ? 64 : 24))) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps (measured, config 3 CFS: limit 24 -> 3.61 ms per solve, 40 -> 3.72, 64 -> 3.97)
                 int *pub = reinterpret_cast<int *>(red_base + 62);
                 int q = 0;                                   // H = QQ: tracked by every thread (one barrier per row); H = I: by wavefront 0
                 for (int s0 = 0; s0 < (IDENT ? 1 : prev_q); ++s0) {
@@ -971,6 +1026,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 }
             }
             STAMP(3);                                       // 3: warm start (H = I) | w gather + rollout (H = QQ, inside the steps)
+            if (cert) fgain = INFINITY;                       // proven infeasible: the loop below leaves at once
             for (;;) {
                 if (fgain > fbound) { qp_status = QP_INFEASIBLE; break; }
                 // step 1: most violated constraint (constraints are strided over the threads; the codes of a
