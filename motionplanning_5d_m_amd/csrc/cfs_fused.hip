@@ -863,9 +863,9 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // integrator), the input bounds to +-racc.  Two collision rows of one waypoint whose normalised sum (weights 1 : w)
             // cannot reach its right side anywhere in that box -- an arm squeezed between two obstacles -- prove the QP
             // infeasible (Farkas, multipliers on the two rows and on box faces).  Config 3: 20-35 % of the infeasible linearisations, 10 % of all
-            // QP steps, +9 % throughput for CFS_FANUC; for PSGCFS_FANUC (opt bit 32) the test costs more than it saves (-7 %).
+            // QP steps, +9 % throughput for CFS_FANUC; for PSGCFS_FANUC the test was measured to cost more than it saves (-7 %).
             bool cert = false;
-            if ((P.has_bounds || (P.opt & 32)) && !(P.opt & 16) && nobs > 1) {      // whole solves and the QP piece (cfs_qp) alike
+            if (!IDENT && P.has_bounds && !(P.opt & 16) && nobs > 1) {      // whole solves and the QP piece (cfs_qp) alike; not compiled into the H = I kernels
                 int hit = 0;
                 for (int e = tid; e < H * nobs; e += FT) {
                     const int i = e / nobs, a = e - i * nobs;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     for (int c = 0; c < NJ; ++c) {
                         const double f = dt * ((double)i + 0.5);
                         double lo = f * (-s_lim[c] - s_v0[c]), hi = f * (s_lim[c] - s_v0[c]);
-                        if (P.has_bounds) { lo = fmax(lo, -s_racc[i * NJ + c]); hi = fmin(hi, s_racc[i * NJ + c]); }
+                        lo = fmax(lo, -s_racc[i * NJ + c]); hi = fmin(hi, s_racc[i * NJ + c]);
                         cen[c] = 0.5 * (lo + hi); rad[c] = fmax(0.5 * (hi - lo), 0.0);
                     }
                     for (int b2 = a + 1; b2 < nobs; ++b2) {
