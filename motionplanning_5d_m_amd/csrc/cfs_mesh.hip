@@ -694,9 +694,22 @@ __global__ __launch_bounds__(64) void mesh_base_kernel(LinMeshParams P)
             int *reci = P.piece_i + (o * MESH_PIECES + pc) * PIECE_I;
             rec[0] = INFINITY; rec[1] = INFINITY; rec[2] = rec[3] = rec[4] = 0.0; reci[0] = -1; reci[1] = 0;   // "nothing within the bound"
             bool go = !(point && pc > 0) && P.meshes[jm].nt > 0;
-            if (go) {
-                const BvhNode nd = P.meshes[jm].nodes[0];
-                go = fmin(node_lower_bound(s6, s6 + 3, nd.lo[0], nd.hi[0]), node_lower_bound(s6, s6 + 3, nd.lo[1], nd.hi[1])) <= bound + margin;
+            if (go) {                                            // box of the piece against the boxes of the root's children (cheap; the
+                const BvhNode nd = P.meshes[jm].nodes[0];        // cut round of stage 2 is cheap too for what slips through)
+                const double lim = bound + margin, lim2 = lim * lim * (1.0 + 1e-13);
+                double g2min = INFINITY;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    double g2 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const double lo = fmin(s6[r], s6[3 + r]), hi = fmax(s6[r], s6[3 + r]);
+                        const double g = fmax(0.0, fmax(nd.lo[c][r] - hi, lo - nd.hi[c][r]));
+                        g2 += g * g;
+                    }
+                    g2min = fmin(g2min, g2);
+                }
+                go = !(g2min * (1.0 - 1e-13) > lim2);
             }
             live = go;
         }
