@@ -862,7 +862,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // confine the position offset of waypoint i to the box dt (i + 1/2) [-lim - v0, lim - v0] (trapezoid rule of the double
             // integrator), the input bounds to +-racc.  Two collision rows of one waypoint whose normalised sum (weights 1 : w)
             // cannot reach its right side anywhere in that box -- an arm squeezed between two obstacles -- prove the QP
-            // infeasible (Farkas, multipliers on the two rows and on box faces).  Config 3: 20-35 % of the infeasible linearisations, 10 % of all
+            // infeasible (Farkas, multipliers on the two rows and on box faces); so do a row of waypoint i and one of waypoint i + 1.  Config 3: 20-35 % of the infeasible linearisations, 10 % of all
             // QP steps, +9 % throughput for CFS_FANUC; for PSGCFS_FANUC the test was measured to cost more than it saves (-7 %).
             bool cert = false;
             if (!IDENT && P.has_bounds && !(P.opt & 16) && nobs > 1) {      // whole solves and the QP piece (cfs_qp) alike; not compiled into the H = I kernels
@@ -901,6 +901,30 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                             if (lhs < rhs_ - 1e-9 * (1.0 + fabs(rhs_) + mag)) hit = 1;
                         }
                     }
+                    // ... and a row of the NEXT waypoint: P_{i+1} = P_i + D with D in dt [-lim - v0, lim - v0] (one trapezoid step), so
+                    // n_a.P_i + w n_b.P_{i+1} <= max over the box of (n_a + w n_b).P_i + max over the step of w n_b.D.  An arm that
+                    // would have to jump between two consecutive waypoints: 57 % of config 3's infeasible linearisations.
+                    if (i + 1 < H)
+                        for (int b2 = 0; b2 < nobs; ++b2) {
+                            double gb[NJ], nb2 = 0.0;
+#pragma unroll
+                            for (int c = 0; c < NJ; ++c) { gb[c] = s_g[(b2 * H + i + 1) * NJ + c]; nb2 += gb[c] * gb[c]; }
+                            if (!(nb2 > 0.0)) continue;
+                            const double ib = 1.0 / sqrt(nb2), rb = -s_rhs[b2 * H + i + 1] * ib;
+#pragma unroll
+                            for (int wk = 0; wk < 3; ++wk) {
+                                const double w = wk == 0 ? 1.0 : (wk == 1 ? 0.5 : 2.0);
+                                double lhs = 0.0, mag = 0.0;
+#pragma unroll
+                                for (int c = 0; c < NJ; ++c) {
+                                    const double cb = w * (gb[c] * ib), cc = ga[c] * ia + cb;
+                                    lhs += (cc * cen[c] + fabs(cc) * rad[c]) + (cb * (-dt * s_v0[c]) + fabs(cb) * (dt * s_lim[c]));
+                                    mag += fabs(cc) * (fabs(cen[c]) + rad[c]) + fabs(cb) * dt * (fabs(s_v0[c]) + s_lim[c]);
+                                }
+                                const double rhs_ = ra + w * rb;
+                                if (lhs < rhs_ - 1e-9 * (1.0 + fabs(rhs_) + mag)) hit = 1;
+                            }
+                        }
                 }
                 cert = block_sum((double)hit, red, tid) > 0.0;     // (no __syncthreads_or: it would add static LDS to a kernel sized to the byte)
             }
