@@ -28,6 +28,10 @@ namespace {
 
 #define STAMP(k) do { if (P.stamps) { const unsigned long long t_ = clock64(); if (tid == 0) s_acc[k] += t_ - t0_; t0_ = t_; } } while (0)
 
+#ifndef CFS_CERT_AT
+#define CFS_CERT_AT 6
+#endif
+constexpr int CERT_AT = CFS_CERT_AT;    // main-loop steps of a QP before the step-free infeasibility certificate is asked
 #ifndef CFS_WG_PER_CU
 #define CFS_WG_PER_CU 1                   // workgroups resident per CU (2: half the LDS and registers each)
 #endif
@@ -863,9 +867,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // integrator), the input bounds to +-racc.  Two collision rows of one waypoint whose normalised sum (weights 1 : w)
             // cannot reach its right side anywhere in that box -- an arm squeezed between two obstacles -- prove the QP
             // infeasible (Farkas, multipliers on the two rows and on box faces); so do a row of waypoint i and one of waypoint i + 1.  Config 3: 20-35 % of the infeasible linearisations, 10 % of all
-            // QP steps, +9 % throughput for CFS_FANUC; for PSGCFS_FANUC the test was measured to cost more than it saves (-7 %).
-            bool cert = false;
-            if (!IDENT && P.has_bounds && !(P.opt & 16) && nobs > 1) {      // whole solves and the QP piece (cfs_qp) alike; not compiled into the H = I kernels
+            // QP steps; with the consecutive-waypoint rows 67 % of them and a quarter of all QP steps: +20 % throughput for CFS_FANUC.
+            // Asked only once a QP has taken CERT_AT steps without finishing (ordinary QPs end in 1-5 steps and never pay for it).
+            // H = I (PSGCFS): measured +-0 in throughput and +0.1 ms on the chain problems of a launch, so not compiled in there.
+            const bool cert_on = !IDENT && !(P.opt & 16) && nobs > 1;   // whole solves and the QP piece (cfs_qp) alike
+            auto certificate = [&]() -> bool {
                 int hit = 0;
                 for (int e = tid; e < H * nobs; e += FT) {
                     const int i = e / nobs, a = e - i * nobs;
@@ -878,7 +884,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     for (int c = 0; c < NJ; ++c) {
                         const double f = dt * ((double)i + 0.5);
                         double lo = f * (-s_lim[c] - s_v0[c]), hi = f * (s_lim[c] - s_v0[c]);
-                        lo = fmax(lo, -s_racc[i * NJ + c]); hi = fmin(hi, s_racc[i * NJ + c]);
+                        if (P.has_bounds) { lo = fmax(lo, -s_racc[i * NJ + c]); hi = fmin(hi, s_racc[i * NJ + c]); }
                         cen[c] = 0.5 * (lo + hi); rad[c] = fmax(0.5 * (hi - lo), 0.0);
                     }
                     for (int b2 = a + 1; b2 < nobs; ++b2) {
@@ -926,8 +932,8 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                             }
                         }
                 }
-                cert = block_sum((double)hit, red, tid) > 0.0;     // (no __syncthreads_or: it would add static LDS to a kernel sized to the byte)
-            }
+                return block_sum((double)hit, red, tid) > 0.0;     // (no __syncthreads_or: it would add static LDS to a kernel sized to the byte)
+            };
             STAMP(1);                                       // 1: QP setup
             // ---- warm start (H = I): begin at the S-pair of the previous outer iteration's active rows ------------------------
             // Consecutive outer iterations linearise nearly the same trajectory, so the optimal active set barely changes (the
@@ -936,7 +942,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // multipliers are >= 0): build P for the previous rows -- Gram products only, wavefront 0 alone, no scan, no combine,
             // no block barrier --, take lambda = -P s(x0), drop rows with lambda <= 0 until none is left, set x = x0 + N lambda.
             // The optimum is the same (strictly convex QP); what changes is the number of steps.
-            if (P.piece == 0 && !cert && !(P.opt & 8) && prev_q > 0 && prev_q <= min(64, P.warm_max > 0 ? P.warm_max : min(PR, IDENT ? 64 : 24))) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps (measured, config 3 CFS: limit 24 -> 3.61 ms per solve, 40 -> 3.72, 64 -> 3.97)
+            if (P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= min(64, P.warm_max > 0 ? P.warm_max : min(PR, IDENT ? 64 : 24))) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps (measured, config 3 CFS: limit 24 -> 3.61 ms per solve, 40 -> 3.72, 64 -> 3.97)
                 int *pub = reinterpret_cast<int *>(red_base + 62);
                 int q = 0;                                   // H = QQ: tracked by every thread (one barrier per row); H = I: by wavefront 0
                 for (int s0 = 0; s0 < (IDENT ? 1 : prev_q); ++s0) {
@@ -1050,9 +1056,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 }
             }
             STAMP(3);                                       // 3: warm start (H = I) | w gather + rollout (H = QQ, inside the steps)
-            if (cert) fgain = INFINITY;                       // proven infeasible: the loop below leaves at once
+            int nloop = 0;
             for (;;) {
                 if (fgain > fbound) { qp_status = QP_INFEASIBLE; break; }
+                if (cert_on && nloop == CERT_AT && certificate()) { qp_status = QP_INFEASIBLE; break; }
+                ++nloop;
                 // step 1: most violated constraint (constraints are strided over the threads; the codes of a
                 // thread's constraints never change, so they are decoded once per kernel -- no integer divisions here)
                 double sbest = 0.0;
