@@ -866,10 +866,11 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // confine the position offset of waypoint i to the box dt (i + 1/2) [-lim - v0, lim - v0] (trapezoid rule of the double
             // integrator), the input bounds to +-racc.  Two collision rows of one waypoint whose normalised sum (weights 1 : w)
             // cannot reach its right side anywhere in that box -- an arm squeezed between two obstacles -- prove the QP
-            // infeasible (Farkas, multipliers on the two rows and on box faces); so do a row of waypoint i and one of waypoint i + 1.  Config 3: 20-35 % of the infeasible linearisations, 10 % of all
-            // QP steps; with the consecutive-waypoint rows 67 % of them and a quarter of all QP steps: +20 % throughput for CFS_FANUC.
-            // Asked only once a QP has taken CERT_AT steps without finishing (ordinary QPs end in 1-5 steps and never pay for it).
-            // H = I (PSGCFS): measured +-0 in throughput and +0.1 ms on the chain problems of a launch, so not compiled in there.
+            // infeasible (Farkas, multipliers on the two rows and on box faces); so do a row of waypoint i and one of waypoint
+            // i + 1 against one trapezoid step.  Config 3: 218 of the 327 infeasible linearisations, a quarter of all QP steps,
+            // +20 % throughput.  Asked only once a QP has taken CERT_AT steps without finishing (ordinary QPs end in 1-5 steps
+            // and never pay for it).  H = I (PSGCFS): measured +-0 in throughput and +0.1 ms on the chain problems of a launch,
+            // so not compiled in there.
             const bool cert_on = !IDENT && !(P.opt & 16) && nobs > 1;   // whole solves and the QP piece (cfs_qp) alike
             auto certificate = [&]() -> bool {
                 int hit = 0;
