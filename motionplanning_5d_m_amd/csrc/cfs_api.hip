@@ -607,7 +607,8 @@ static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
     fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
     fp.x0 = p->x0.p;
     fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(p->nn);
-    fp.opt = g_opt;
+    fp.opt = g_opt ^ 1;       // bit 1 of the kernel's switch word = roll w = H^{-1} n_p out in LDS (default since round 2: +2-4 % on config 3
+                              // CFS, a third of the gather's L2 loads); CFS_OPT=1 loads the precomputed rollouts of the family matrices instead
     fp.polish_tol = g_polish_tol;
     fp.warm_max = g_warm_max;
 }
