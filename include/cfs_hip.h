@@ -194,6 +194,15 @@ int cfs_build_terms_device(cfs_problem *p, int B, const double *x0, const double
 int cfs_build_terms_from_routes_device(cfs_problem *p, int B, const double *routes, int nwp,
                                        double *x_init, double *xR1, double *ff, double *caug, void *stream);
 
+/* ---- baseline cost ---------------------------------------------------------------------------
+ * replaces: Cost_b = EVAL(sys_info).get_Cost_b() (Lib/EVAL.m:75-78, called at main_FANUC.m:131-132) for B problems of the
+ * handle's family: u_b = quadprog(Qaug, paug) without constraints = -H^{-1} ff (H = QQ symmetrised, as quadprog does),
+ * cost_b = get_cost(u_b) = 0.5*u_b'*QQ*u_b + ff'*u_b + caug (Lib/EVAL.m:51-53).  HOST pointers.  ff: B x nn; caug: B;
+ * cost_b: B; u_b: B x nn (may be NULL).  Works for handles of either mode (the family's QQ is the same). */
+int cfs_cost_b(cfs_problem *p, int B, const double *ff, const double *caug, double *cost_b, double *u_b);
+/* replaces: cost = self.eval.get_cost(u) (Lib/EVAL.m:51-53) for B given u (B x nn): 0.5*u'*QQ*u + ff'*u + caug.  HOST pointers. */
+int cfs_get_cost(cfs_problem *p, int B, const double *u, const double *ff, const double *caug, double *cost);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * When enabled, cfs_solve_batch_device brackets each kernel launch with hipEvents recorded on the
  * caller's stream (the reference has only tic/toc around the solver calls, main_FANUC.m:140-152).
@@ -280,6 +289,34 @@ int cfs_problem_set_meshes(cfs_problem *p, int nmesh, const cfs_mesh *const *mes
  * i*njoint,:), dm_f without the M200i joint offset, derivest derivatives): see csrc/cfs_chomp.hip for the list. */
 int cfs_chomp_batch(cfs_problem *p, const cfs_batch_in *in, const double *u0, const double *D, const double *epsilon,
                     const cfs_batch_out *out);
+
+/* ---- developer / test entry points -------------------------------------------------------------------
+ * No caller of the path needs these; they exist so that every shortcut the solver takes can be switched off and compared
+ * under pytest (tests/test_gpu_shortcuts.py), and for the cycle-stamp / step-trace probes under tools/.  All state is per
+ * handle: nothing is read from the environment, nothing is process-wide.  Results with and without each switch are the
+ * same optimum of the same strictly convex QPs; what the tests assert bit for bit, and what to a tolerance, is stated there. */
+#define CFS_DBG_GATHER_ROLLOUTS 1   /* H = QQ: load the precomputed rollouts of the family-matrix columns instead of prefix sums in LDS */
+#define CFS_DBG_NO_REFINE 2         /* no iterative refinement of the step directions                                                  */
+#define CFS_DBG_NO_WARM_START 8     /* every QP starts from the empty active set                                                       */
+#define CFS_DBG_NO_CERTIFICATE 16   /* CFS_FANUC: no step-free infeasibility certificate (infeasible QPs are proven by the dual steps)  */
+#define CFS_DBG_NO_PRUNE 32         /* num_jac evaluates every link at every evaluation point (no candidate pruning)                    */
+#define CFS_DBG_NO_AUTO_ORDER 64    /* no automatic launch order                                                                       */
+#define CFS_DBG_TIER_W1 128         /* one workgroup per compute unit (64 register-resident columns of the inverse Gram matrix)         */
+/* mask: OR of CFS_DBG_*; warm_max: largest previous active set a warm start takes (0 = default: 24 rows for CFS_FANUC, the
+ * register-resident columns for PSGCFS_FANUC; <= 64); polish_tol: relative drift of an active row at the optimum that
+ * triggers the projection (<= 0 = default 1e-11).  Applies to the following solves / pieces of this handle. */
+int cfs_debug_set_options(cfs_problem *p, int mask, int warm_max, double polish_tol);
+/* cycle stamps: B > 0, out == NULL: enable for the next solves of <= B problems; out != NULL: read 12 accumulators per
+ * problem (HOST pointer, synchronises); B <= 0, out == NULL: off */
+int cfs_debug_stamps(cfs_problem *p, int B, unsigned long long *out);
+/* trace of the active-set steps of problem b: 8 doubles per step, at most cap steps; cap <= 0: off.
+ * cfs_debug_trace_read: out = (cap+1)*8 doubles (HOST), out[0] = number of records */
+int cfs_debug_trace_begin(cfs_problem *p, int b, int cap);
+int cfs_debug_trace_read(cfs_problem *p, double *out);
+/* log of u after every outer iteration (either solver; the solve itself is unchanged): on != 0 allocates
+ * max_batch x MAX_O_ITER x nn doubles; cfs_debug_read_u_log copies the first B problems to `out` (HOST) */
+int cfs_debug_log_u(cfs_problem *p, int on);
+int cfs_debug_read_u_log(cfs_problem *p, int B, double *out);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,10 @@
 //   [Ainq, binq] = cfs_mex('get_con', mode, obs, sys_info, ROBOT, x_, u)   % self.get_con() (Lib/CFS_FANUC.m:101-135): dense, reference row order
 //   [u, x_, cost_all, e_cost_all, e_u_all, iter_O] = cfs_mex('chomp', obs_, sys_info, ROBOT, uref)   % CHOMP_FANUC.optimizer (Lib/CHOMP_FANUC.m:54-69);
 //        obs_ = the reference's cell: obs_{1}.num_obs followed by the obstacles (M16iB/CHOMP.m:26-29)
+//   [d, linkid] = cfs_mex('dist_arm', theta, obs_l, robot, ROBOT)  % dist_arm_3D_200i_2 / dist_arm_3D_Heu_2 / dist_arm_2L(theta, base, obs_l, robot)
+//        theta = njoint x N (one pose per column), obs_l = 3x2 obstacle axis (or 6 x nobs, one [l(:,1); l(:,2)] per column): the
+//        geometry kernel RRT_FANUC.feasible (Lib/RRT_FANUC.m:146-181) and get_con (Lib/CFS_FANUC.m:115) call; d, linkid = nobs x N
+//   Cost_b = cfs_mex('cost_b', sys_info, ROBOT)                    % EVAL.get_Cost_b (Lib/EVAL.m:75-78, main_FANUC.m:131-132)
 //   h = cfs_mex('mesh_load_stl', path, scale, map_from_stl)        % Lib/functions/MapFromSTL.m
 //   [dis, points] = cfs_mex('mesh_segment_distance', h, seg6)      % point2surface_dis (M200i/dist_arm_surf_200i.m:21)
 //   cfs_mex('mesh_destroy', h)
@@ -55,7 +59,7 @@ struct Family {
     std::vector<double> margin, obs6, Dv, epsv;
     ~Family() { if (p) cfs_problem_destroy(p); }
 };
-static void make_family(Family &f, int mode, const mxArray *obs, int first, int nobs, const mxArray *S, const char *ROBOT)
+static void make_family(Family &f, int mode, const mxArray *obs, int first, int nobs, const mxArray *S, const char *ROBOT, bool need_both = false)
 {
     cfs_problem_desc &d = f.d;
     memset(&d, 0, sizeof d);
@@ -74,13 +78,24 @@ static void make_family(Family &f, int mode, const mxArray *obs, int first, int 
     std::vector<const cfs_mesh *> meshes;
     for (int j = 0; j < nobs; ++j) {
         const mxArray *o = mxGetCell(obs, first + j);
-        f.Dv[j] = mxGetScalar(mxGetField(o, 0, "D"));
-        f.epsv[j] = mxGetScalar(mxGetField(o, 0, "epsilon"));
-        f.margin[j] = mode == CFS_MODE_CFS ? f.epsv[j] : f.Dv[j];                         // CFS_FANUC.m:117 | PSGCFS_FANUC.m:158
+        if (!o) mexErrMsgIdAndTxt("cfs:obs", "obs{%d} is empty", first + j + 1);
+        // the margin field the mode reads must exist (CFS_FANUC.m:117 reads .epsilon, PSGCFS_FANUC.m:158 reads .D); the other one is
+        // optional (0) -- a cell written for one solver need not carry the other solver's field
+        const mxArray *fD = mxGetField(o, 0, "D"), *fE = mxGetField(o, 0, "epsilon");
+        if (!(mode == CFS_MODE_CFS ? fE : fD))
+            mexErrMsgIdAndTxt("cfs:obs", "obs{%d}.%s is missing", first + j + 1, mode == CFS_MODE_CFS ? "epsilon" : "D");
+        if (need_both && !(fD && fE)) mexErrMsgIdAndTxt("cfs:obs", "obs_{%d} needs both .D and .epsilon (Lib/CHOMP_FANUC.m:95-96)", first + j + 1);
+        f.Dv[j] = fD ? mxGetScalar(fD) : 0.0;
+        f.epsv[j] = fE ? mxGetScalar(fE) : 0.0;
+        f.margin[j] = mode == CFS_MODE_CFS ? f.epsv[j] : f.Dv[j];
         const mxArray *mh = mxGetField(o, 0, "mesh");
         if (mh) meshes.push_back(mesh_of(mh));
         else if (!meshes.empty()) mexErrMsgTxt("mesh obstacles must come last in the obs cell");
-        else memcpy(&f.obs6[6 * (size_t)j], mxGetPr(mxGetField(o, 0, "l")), sizeof(double) * 6);   // [l(:,1); l(:,2)]
+        else {
+            const mxArray *fl = mxGetField(o, 0, "l");
+            if (!fl || mxGetNumberOfElements(fl) != 6) mexErrMsgIdAndTxt("cfs:obs", "obs{%d}.l must be 3x2", first + j + 1);
+            memcpy(&f.obs6[6 * (size_t)j], mxGetPr(fl), sizeof(double) * 6);   // [l(:,1); l(:,2)]
+        }
     }
     d.margin = f.margin.data();
     check(cfs_problem_create(&d, &f.p));
@@ -137,7 +152,7 @@ static void chomp(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     const std::string ROBOT = mxArrayToString(prhs[3]);
     const int nobs = (int)mxGetScalar(mxGetField(mxGetCell(prhs[1], 0), 0, "num_obs"));    // obs_{1}.num_obs (M16iB/CHOMP.m:26)
     Family f;
-    make_family(f, CFS_MODE_CFS, prhs[1], 1, nobs, S, ROBOT.c_str());
+    make_family(f, CFS_MODE_CFS, prhs[1], 1, nobs, S, ROBOT.c_str(), true);
     const int nn = f.d.H * f.d.njoint, nx = f.d.H * 2 * f.d.njoint, K = f.d.MAX_O_ITER;
     double caug = field_scalar(S, "caug");
     cfs_batch_in in;
@@ -156,6 +171,48 @@ static void chomp(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     for (int k = 0; k < 6; ++k) { if (k < nlhs || k == 0) plhs[k] = outs[k]; else mxDestroyArray(outs[k]); }
 }
 
+// [d, linkid] = dist_arm_*(theta, base, obs_l, robot) for N poses x nobs obstacle axes: the primitive under RRT_FANUC.feasible
+// (Lib/RRT_FANUC.m:146-181) and get_con (Lib/CFS_FANUC.m:115); matlab/dist_arm_3D_200i_2.m is the one-line shim over it
+static void dist_arm(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
+{
+    if (nrhs < 5) mexErrMsgTxt("[d, linkid] = cfs_mex('dist_arm', theta, obs_l, robot, ROBOT)");
+    const std::string ROBOT = mxArrayToString(prhs[4]);
+    const int nj = (int)mxGetM(prhs[1]), N = (int)mxGetN(prhs[1]);
+    if (mxGetNumberOfElements(prhs[2]) % 6) mexErrMsgTxt("obs_l must be 3x2 (or 6 x nobs)");
+    const int nobs = (int)(mxGetNumberOfElements(prhs[2]) / 6);
+    cfs_robot r;
+    fill_robot(prhs[3], ROBOT.c_str(), nj, r);
+    std::vector<double> d((size_t)N * nobs);
+    std::vector<int> lid((size_t)N * nobs);
+    check(cfs_dist_arm(&r, nj, N, mxGetPr(prhs[1]), nobs, mxGetPr(prhs[2]), d.data(), lid.data(), nullptr));   // theta njoint x N column-major = N x njoint row-major
+    mxArray *od = mxCreateDoubleMatrix(nobs, N, mxREAL), *ol = mxCreateDoubleMatrix(nobs, N, mxREAL);
+    for (size_t k = 0; k < d.size(); ++k) { mxGetPr(od)[k] = d[k]; mxGetPr(ol)[k] = lid[k]; }               // N x nobs row-major = nobs x N column-major
+    plhs[0] = od;
+    if (nlhs > 1) plhs[1] = ol; else mxDestroyArray(ol);
+}
+
+// Cost_b = EVAL(sys_info).get_Cost_b()  (Lib/EVAL.m:75-78)
+static void cost_b(mxArray *plhs[], int nrhs, const mxArray *prhs[])
+{
+    if (nrhs < 3) mexErrMsgTxt("Cost_b = cfs_mex('cost_b', sys_info, ROBOT)");
+    const mxArray *S = prhs[1];
+    const std::string ROBOT = mxArrayToString(prhs[2]);
+    Family f;
+    cfs_problem_desc &d = f.d;
+    memset(&d, 0, sizeof d);
+    d.mode = CFS_MODE_CFS;
+    d.H = (int)field_scalar(S, "H"); d.njoint = (int)field_scalar(S, "njoint"); d.nobs = 1;
+    fill_robot(mxGetField(S, 0, "robot"), ROBOT.c_str(), d.njoint, d.robot);
+    d.QQ = field_ptr(S, "QQ"); d.lim = field_ptr(S, "lim"); d.MAX_input = field_ptr(S, "MAX_input");
+    d.epsilon_O = field_scalar(S, "epsilon_O"); d.MAX_O_ITER = (int)field_scalar(S, "MAX_O_ITER"); d.max_batch = 1;
+    const double zero = 0.0;
+    d.margin = &zero;
+    check(cfs_problem_create(&d, &f.p));
+    double caug = field_scalar(S, "caug"), cost = 0.0;
+    check(cfs_cost_b(f.p, 1, field_ptr(S, "ff"), &caug, &cost, nullptr));
+    plhs[0] = mxCreateDoubleScalar(cost);
+}
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
     if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgTxt("cfs_mex(command, ...)");
@@ -166,6 +223,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         get_con(nlhs, plhs, nrhs, prhs);
     } else if (cmd == "chomp") {
         chomp(nlhs, plhs, nrhs, prhs);
+    } else if (cmd == "dist_arm") {
+        dist_arm(nlhs, plhs, nrhs, prhs);
+    } else if (cmd == "cost_b") {
+        cost_b(plhs, nrhs, prhs);
     } else if (cmd == "mesh_load_stl") {
         cfs_mesh *m = nullptr;
         check(cfs_mesh_load_stl(mxArrayToString(prhs[1]), nrhs > 2 ? mxGetScalar(prhs[2]) : 1.0, nrhs > 3 && mxGetScalar(prhs[3]) != 0, &m));

@@ -18,7 +18,7 @@ except Exception:  # pragma: no cover - torch is optional for the host-pointer e
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, os.environ.get("CFS_LIBNAME", "libcfs_hip.so"))   # CFS_LIBNAME: developer A/B builds
+LIB_PATH = os.path.join(_HERE, "libcfs_hip.so")
 
 CFS_MAX_LINKS = 8
 CFS_MAX_OBS = 32
@@ -139,7 +139,18 @@ SYMBOLS = [
     ("cfs_dist_arm_mesh", C.c_int, [C.POINTER(cfs_robot), C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     ("cfs_problem_set_meshes", C.c_int, [_P, C.c_int, _P]),
     ("cfs_chomp_batch", C.c_int, [_P, C.POINTER(cfs_batch_in), _P, _P, _P, C.POINTER(cfs_batch_out)]),
+    ("cfs_cost_b", C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    ("cfs_get_cost", C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    ("cfs_debug_set_options", C.c_int, [_P, C.c_int, C.c_int, C.c_double]),
+    ("cfs_debug_stamps", C.c_int, [_P, C.c_int, _P]),
+    ("cfs_debug_trace_begin", C.c_int, [_P, C.c_int, C.c_int]),
+    ("cfs_debug_trace_read", C.c_int, [_P, _P]),
+    ("cfs_debug_log_u", C.c_int, [_P, C.c_int]),
+    ("cfs_debug_read_u_log", C.c_int, [_P, C.c_int, _P]),
 ]
+
+# cfs_debug_set_options mask bits (include/cfs_hip.h)
+DBG = {"gather_rollouts": 1, "no_refine": 2, "no_warm_start": 8, "no_certificate": 16, "no_prune": 32, "no_auto_order": 64, "tier_w1": 128}
 
 _lib = None
 

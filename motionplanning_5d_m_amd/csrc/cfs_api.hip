@@ -178,7 +178,8 @@ struct cfs_problem {
     // workspace (max_batch problems)
     DevBuf<double> x0, qu, dist, grad, Yg, Pt, u_hist, qu_hist;
     DevBuf<int> noise_row, linkid;
-    DevBuf<int> order, okey;   // launch order of the fused solver: automatic (violation count of the initial trajectory), given, or identity
+    DevBuf<int> order, okey;   // launch order of the fused solver, automatic: violation count of the initial trajectory -> rank
+    DevBuf<int> order_user;    // the caller's permutation (cfs_set_launch_order); a solve of another batch size falls back to the automatic order
     int n_cu = 256;            // compute units of the handle's device: a batch of at most n_cu problems starts all at once
     int order_mode = 0, order_n = 0;   // 0 automatic, 1 given (order_n entries), 2 identity
     // mesh obstacles (cfs_problem_set_meshes): the last nmesh of the nobs obstacles
@@ -186,6 +187,14 @@ struct cfs_problem {
     DevBuf<DevMesh> meshes_d;
     DevBuf<double> st_cost, m_ends, m_base, m_shift, m_upper, m_pd, m_pnd;
     DevBuf<int> st_done, m_tri, m_near, m_pi;
+    // developer / test switches (cfs_debug_*, include/cfs_hip.h): per handle, no process-wide state
+    int dbg_mask = 0, dbg_warm_max = 0;
+    double dbg_polish_tol = 1e-11;        // = the constraint scan's own feasibility tolerance
+    DevBuf<unsigned long long> stamps;    // 12 cycle accumulators per problem
+    int stamps_B = 0;
+    DevBuf<double> trace;                 // 8 doubles per active-set step of problem trace_b
+    int trace_b = -1, trace_cap = 0;
+    DevBuf<double> u_log;                 // max_batch x MAX_O_ITER x nn: u after every outer iteration (both solvers)
     bool prof = false;
     std::vector<hipEvent_t> ev;   // 4 per profiled solve: gemm start/stop, fused start/stop
     std::vector<hipEvent_t> ev_free;   // recycled events: none is created inside a timed region once the pool is warm
@@ -199,26 +208,13 @@ struct cfs_problem {
         for (auto &m : Mr) m.release();
         F1.release(); F2.release(); Cq.release(); cost.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
-        grad.release(); Yg.release(); noise_row.release(); order.release(); okey.release();
+        grad.release(); Yg.release(); noise_row.release(); order.release(); okey.release(); order_user.release();
         linkid.release(); meshes_d.release(); st_cost.release(); st_done.release();
         m_ends.release(); m_base.release(); m_shift.release(); m_tri.release(); m_near.release(); m_upper.release();
         m_pd.release(); m_pnd.release(); m_pi.release();
+        stamps.release(); trace.release(); u_log.release();
     }
 };
-
-// developer aid (not part of the ABI header): trace the active-set steps of one problem of the next solves
-static unsigned long long *g_stamps = nullptr;
-static int g_stamps_B = 0;
-static double *g_dbg = nullptr;
-static int g_dbg_b = -1, g_dbg_cap = 0;
-// developer A/B switches, read once at load time.  (Named functions: lambdas in namespace-scope initialisers all mangle to
-// {lambda()#1} and the out-of-line copy of one was called for another.)
-static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
-static double env_double(const char *name, double dflt) { const char *e = getenv(name); return e ? atof(e) : dflt; }
-static const int g_opt = env_int("CFS_OPT", 0);
-static const double g_polish_tol = env_double("CFS_POLISH_TOL", 1e-11);   // = the scan's feasibility tolerance
-static const int g_warm_max = env_int("CFS_WARM_MAX", 0);
-static int g_no_prune = 0;       // cfs_debug_no_prune: linearise without candidate pruning (test of the pruning's bit-exactness)
 
 int cfs_fail(int code, const char *fmt, ...)
 {
@@ -233,46 +229,17 @@ void cfs_build_dev_robot(const cfs_robot &r, DevRobot &d) { build_dev_robot(r, d
 
 // Tier of the fused kernel (cfs_device.h).  Two problems per CU win whenever they fit: measured on config 3, PSGCFS
 // 3.6 -> 2.3 ms per solve with w2s, CFS 5.8 -> 5.6 ms with w2m (its infeasibility proofs run active sets of ~100 rows).
-// CFS_TIER=w1|w2m|w2s overrides (developer A/B).
+// w2s is compiled for the identity Hessian only (PSGCFS), w2m for QQ only (CFS), w1 for both; force_w1: CFS_DBG_TIER_W1.
 bool fused_fits(int nj, int H, int nobs) { return fused_fits_w1(nj, H, nobs); }
-hipError_t launch_fused(int nj, FusedParams p, hipStream_t s)
+hipError_t launch_fused(int nj, FusedParams p, hipStream_t s, bool force_w1)
 {
-    // w2s is compiled for the identity Hessian only (PSGCFS), w2m for QQ only (CFS), w1 for both
-    static const char *force = getenv("CFS_TIER");
     const bool ident = p.mode == CFS_MODE_PSGCFS;
-    int tier = ident ? 2 : 1;
-    if (force && !strcmp(force, "w1")) tier = 0;
-    if (tier == 2 && fused_fits_w2s(nj, p.H, p.nobs)) return launch_fused_w2s(nj, p, s);
-    if (tier == 1 && fused_fits_w2m(nj, p.H, p.nobs)) return launch_fused_w2m(nj, p, s);
+    if (!force_w1 && ident && fused_fits_w2s(nj, p.H, p.nobs)) return launch_fused_w2s(nj, p, s);
+    if (!force_w1 && !ident && fused_fits_w2m(nj, p.H, p.nobs)) return launch_fused_w2m(nj, p, s);
     return launch_fused_w1(nj, p, s);
 }
 
 extern "C" {
-
-int cfs_debug_trace_begin(int b, int cap)
-{
-    if (g_dbg) { (void)hipFree(g_dbg); g_dbg = nullptr; }
-    g_dbg_b = b; g_dbg_cap = cap;
-    if (cap <= 0) return 0;
-    if (hipMalloc(reinterpret_cast<void **>(&g_dbg), (size_t)(cap + 1) * 8 * sizeof(double)) != hipSuccess) return -1;
-    return hipMemset(g_dbg, 0, (size_t)(cap + 1) * 8 * sizeof(double)) == hipSuccess ? 0 : -1;
-}
-int cfs_debug_stamps(int B, unsigned long long *out)   /* B>0,out==NULL: enable for B problems; out!=NULL: read 12 per problem; B==0: off */
-{
-    if (out) { if (!g_stamps) return -1; if (hipDeviceSynchronize() != hipSuccess) return -1; return hipMemcpy(out, g_stamps, (size_t)g_stamps_B * 12 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
-    if (g_stamps) { (void)hipFree(g_stamps); g_stamps = nullptr; }
-    g_stamps_B = B;
-    if (B <= 0) return 0;
-    if (hipMalloc(reinterpret_cast<void **>(&g_stamps), (size_t)B * 12 * 8) != hipSuccess) return -1;
-    return hipMemset(g_stamps, 0, (size_t)B * 12 * 8) == hipSuccess ? 0 : -1;
-}
-int cfs_debug_no_prune(int on) { g_no_prune = on != 0; return 0; }
-int cfs_debug_trace_read(double *out)   /* out: (cap+1)*8 doubles; out[0] = number of records */
-{
-    if (!g_dbg) return -1;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpy(out, g_dbg, (size_t)(g_dbg_cap + 1) * 8 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
-}
 
 int cfs_abi_version(void) { return CFS_ABI_VERSION; }
 const char *cfs_last_error(void) { return g_err; }
@@ -451,7 +418,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
     A_(Yg, Bm * nn * nn);
     if (desc->mode == CFS_MODE_CFS) { A_(u_hist, Bm * (size_t)desc->MAX_O_ITER * nn); A_(qu_hist, Bm * (size_t)desc->MAX_O_ITER * nn); }
-    A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H); A_(order, Bm); A_(okey, Bm);
+    A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H); A_(order, Bm); A_(okey, Bm); A_(order_user, Bm);
 #undef A_
 #define U_(buf, src, count) if (e == hipSuccess) e = hipMemcpy(p->buf.p, src, (count) * sizeof(*p->buf.p), hipMemcpyHostToDevice)
     U_(rb, &p->hrobot, 1); U_(QQ, desc->QQ, (size_t)nn * nn); U_(Hinv, Hinv.data(), (size_t)nn * nn);
@@ -607,13 +574,18 @@ static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
     fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
     fp.x0 = p->x0.p;
     fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(p->nn);
-    fp.opt = g_opt ^ 1;       // bit 1 of the kernel's switch word = roll w = H^{-1} n_p out in LDS (default since round 2: +2-4 % on config 3
-                              // CFS, a third of the gather's L2 loads); CFS_OPT=1 loads the precomputed rollouts of the family matrices instead
-    fp.polish_tol = g_polish_tol;
-    fp.warm_max = g_warm_max;
+    // kernel switch word: bit 0 = roll w = H^{-1} n_p out in LDS (the default since round 2: +2-4 % on config 3 CFS, a third of the
+    // gather's L2 loads; CFS_DBG_GATHER_ROLLOUTS loads the precomputed rollouts of the family matrices instead), bit 1 = no
+    // refinement, bit 3 = no warm start, bit 4 = no step-free certificate
+    fp.opt = ((p->dbg_mask & CFS_DBG_GATHER_ROLLOUTS) ? 0 : 1) | (p->dbg_mask & (CFS_DBG_NO_REFINE | CFS_DBG_NO_WARM_START | CFS_DBG_NO_CERTIFICATE));
+    fp.polish_tol = p->dbg_polish_tol;
+    fp.warm_max = p->dbg_warm_max;
+    fp.no_prune = (p->dbg_mask & CFS_DBG_NO_PRUNE) ? 1 : 0;
+    fp.dbg = p->trace.p; fp.dbg_b = p->trace_b; fp.dbg_cap = p->trace_cap;
+    fp.stamps = (p->stamps.p && B <= p->stamps_B) ? p->stamps.p : nullptr;
+    fp.u_log = p->u_log.p;
 }
-
-static const int g_order_off = env_int("CFS_ORDER", 1) == 0;   // CFS_ORDER=0: developer A/B, no automatic order
+static bool force_w1(const cfs_problem *p) { return (p->dbg_mask & CFS_DBG_TIER_W1) != 0; }
 
 int cfs_set_launch_order(cfs_problem *p, const int *order, int n)
 {
@@ -627,10 +599,12 @@ int cfs_set_launch_order(cfs_problem *p, const int *order, int n)
     }
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipDeviceSynchronize());      // a solve in flight may still be reading the previous order
-    HIPCHK(hipMemcpy(p->order.p, order, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->order_user.p, order, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     p->order_mode = 1; p->order_n = n;
     return CFS_SUCCESS;
 }
+
+static int enqueue_solve(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, hipStream_t s, hipEvent_t *e4);
 
 int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, void *stream)
 {
@@ -642,14 +616,24 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
         return fail(CFS_ERR_INVALID_ARG, "NULL output array");
     HIPCHK(hipSetDevice(p->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int nj = p->d.njoint, nn = p->nn, nx = p->nx, K = p->d.MAX_O_ITER;
 
     hipEvent_t e4[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = CFS_SUCCESS;
     if (p->prof)
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4 && rc == CFS_SUCCESS; ++k) {
             if (!p->ev_free.empty()) { e4[k] = p->ev_free.back(); p->ev_free.pop_back(); }
-            else HIPCHK(hipEventCreate(&e4[k]));
+            else if (hipEventCreate(&e4[k]) != hipSuccess) { e4[k] = nullptr; rc = fail(CFS_ERR_HIP, "hipEventCreate failed"); }
         }
+    if (rc == CFS_SUCCESS) rc = enqueue_solve(p, in, out, s, e4);
+    if (p->prof)                         // recorded events are read by cfs_profile_read; after an error they go back to the pool
+        for (int k = 0; k < 4; ++k)
+            if (e4[k]) (rc == CFS_SUCCESS ? p->ev : p->ev_free).push_back(e4[k]);
+    return rc;
+}
+
+static int enqueue_solve(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, hipStream_t s, hipEvent_t *e4)
+{
+    const int B = in->B, nj = p->d.njoint, nn = p->nn, K = p->d.MAX_O_ITER;
     if (p->prof) HIPCHK(hipEventRecord(e4[0], s));
     if (p->d.mode == CFS_MODE_CFS) {     // unconstrained minimiser -H^{-1} ff (MFMA), constant over the outer loop
         GemvParams g;
@@ -663,26 +647,22 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
     fp.x_init = in->x_init; fp.xR1 = in->xR1; fp.ff = in->ff; fp.caug = in->caug; fp.obs = in->obs; fp.noise = in->noise;
     fp.u = out->u; fp.x_ = out->x_; fp.cost_all = out->cost_all; fp.e_cost_all = out->e_cost_all; fp.e_u_all = out->e_u_all;
     fp.iter_O = out->iter_O; fp.total_iter = out->total_iter; fp.status = out->status;
-    fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
-    fp.stamps = (g_stamps && B <= g_stamps_B) ? g_stamps : nullptr;
     fp.u_hist = (p->d.mode == CFS_MODE_CFS && K > 0) ? p->u_hist.p : nullptr;
-    fp.no_prune = g_no_prune;
     // Launch order.  Workgroups are dispatched in blockIdx order and a launch ends with its longest problem, so problems
     // that will run long active sets should not wait for a free compute unit behind short ones.  Automatic: a pre-pass
     // counts the clearances the initial trajectory violates (two small kernels on the same stream, ~10 us) -- only when the
     // batch cannot start all at once anyway.
     const int nline = p->d.nobs - p->nmesh;
-    if (p->order_mode == 1 && p->order_n == B) fp.order = p->order.p;
-    else if (p->order_mode == 0 && !g_order_off && B > p->n_cu && nline > 0) {
+    if (p->order_mode == 1 && p->order_n == B) fp.order = p->order_user.p;
+    else if (p->order_mode != 2 && !(p->dbg_mask & CFS_DBG_NO_AUTO_ORDER) && B > p->n_cu && nline > 0) {   // also when a given order is for another batch size
         OrderParams op;
         op.rb = p->rb.p; op.B = B; op.H = p->d.H; op.nj = nj; op.nobs = nline; op.obs_stride = p->d.nobs;
         op.x_init = in->x_init; op.obs = in->obs; op.margin = p->margin.p; op.key = p->okey.p; op.order = p->order.p;
         launch_order(op, s);
         fp.order = p->order.p;
     }
-    (void)nx;
     if (p->nmesh == 0) {
-        HIPCHK(launch_fused(nj, fp, s));
+        HIPCHK(launch_fused(nj, fp, s, force_w1(p)));
     } else {
         // Mesh obstacles are linearised by their own kernel (hierarchy traversals do not fit the fused kernel's register
         // budget), which needs the current iterate: one outer iteration per launch, state carried through HBM.  Every
@@ -699,13 +679,10 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
             lm.seed_prev = it > 0;
             HIPCHK(launch_linearize_mesh(nj, lm, s));
             fp.resume = it > 0;
-            HIPCHK(launch_fused(nj, fp, s));
+            HIPCHK(launch_fused(nj, fp, s, force_w1(p)));
         }
     }
-    if (p->prof) {
-        HIPCHK(hipEventRecord(e4[3], s));
-        for (int k = 0; k < 4; ++k) p->ev.push_back(e4[k]);
-    }
+    if (p->prof) HIPCHK(hipEventRecord(e4[3], s));
     if (fp.u_hist) {                     // CFS cost history: QQ * (all logged u) on the matrix cores, then the dots
         if (p->u_hist.n) {
             GemvParams g;
@@ -762,6 +739,142 @@ int cfs_solve_batch(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out 
     st.down(out->total_iter, dout.total_iter, B);
     st.down(out->status, dout.status, B);
     if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+// ---- EVAL.get_Cost_b (Lib/EVAL.m:75-78; main_FANUC.m:131-132) ----------------------------------------------------------
+// u_b = quadprog(Qaug, paug) with no constraints = -H^{-1} ff (H = QQ symmetrised, as quadprog does), cost = get_cost(u_b):
+// two products on the matrix cores (the first is the one every CFS solve starts with) and one dot per problem.
+int cfs_cost_b(cfs_problem *p, int B, const double *ff, const double *caug, double *cost_b, double *u_b)
+{
+    if (!p || !ff || !caug || !cost_b) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    if (B < 1 || B > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "B=%d outside 1..max_batch=%d", B, p->d.max_batch);
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nn = p->nn;
+    Stage st;
+    const double *d_ff = st.up(ff, B * nn), *d_caug = st.up(caug, (size_t)B);
+    double *d_cost = st.up<double>(nullptr, (size_t)B);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    GemvParams g;
+    g.B = B; g.nn = (int)nn; g.M = p->Hinv.p; g.X = d_ff; g.Y = p->x0.p; g.scale = -1.0;
+    launch_batched_gemv(g, nullptr);
+    g.M = p->QQ.p; g.X = p->x0.p; g.Y = p->qu.p; g.scale = 1.0;
+    launch_batched_gemv(g, nullptr);
+    CostHistParams ch;
+    memset(&ch, 0, sizeof ch);
+    ch.B = B; ch.nn = (int)nn; ch.max_o_iter = 1; ch.u_hist = p->x0.p; ch.qu_hist = p->qu.p; ch.ff = d_ff; ch.caug = d_caug;
+    ch.iter_O = nullptr; ch.cost_all = d_cost; ch.e_cost_all = nullptr;      // iter_O == NULL: one logged iterate per problem
+    launch_cost_history(ch, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    st.down(cost_b, d_cost, (size_t)B);
+    if (u_b) st.down(u_b, p->x0.p, B * nn);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+// cost = self.eval.get_cost(u) (Lib/EVAL.m:51-53) for B given u: QQ*u on the matrix cores, one dot per problem
+int cfs_get_cost(cfs_problem *p, int B, const double *u, const double *ff, const double *caug, double *cost)
+{
+    if (!p || !u || !ff || !caug || !cost) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    if (B < 1 || B > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "B=%d outside 1..max_batch=%d", B, p->d.max_batch);
+    HIPCHK(hipSetDevice(p->device));
+    const size_t nn = p->nn;
+    Stage st;
+    const double *d_u = st.up(u, B * nn), *d_ff = st.up(ff, B * nn), *d_caug = st.up(caug, (size_t)B);
+    double *d_cost = st.up<double>(nullptr, (size_t)B);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "staging failed: %s", hipGetErrorString(st.err));
+    GemvParams g;
+    g.B = B; g.nn = (int)nn; g.M = p->QQ.p; g.X = d_u; g.Y = p->qu.p; g.scale = 1.0;
+    launch_batched_gemv(g, nullptr);
+    CostHistParams ch;
+    memset(&ch, 0, sizeof ch);
+    ch.B = B; ch.nn = (int)nn; ch.max_o_iter = 1; ch.u_hist = d_u; ch.qu_hist = p->qu.p; ch.ff = d_ff; ch.caug = d_caug; ch.cost_all = d_cost;
+    launch_cost_history(ch, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    st.down(cost, d_cost, (size_t)B);
+    if (st.err != hipSuccess) return fail(CFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(st.err));
+    return CFS_SUCCESS;
+}
+
+// ---- developer / test entry points (declared in include/cfs_hip.h; per handle) --------------------------------------------
+int cfs_debug_set_options(cfs_problem *p, int mask, int warm_max, double polish_tol)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    const int known = CFS_DBG_GATHER_ROLLOUTS | CFS_DBG_NO_REFINE | CFS_DBG_NO_WARM_START | CFS_DBG_NO_CERTIFICATE | CFS_DBG_NO_PRUNE |
+                      CFS_DBG_NO_AUTO_ORDER | CFS_DBG_TIER_W1;
+    if (mask & ~known) return fail(CFS_ERR_INVALID_ARG, "unknown option bits 0x%x", mask & ~known);
+    if (warm_max < 0 || warm_max > 64) return fail(CFS_ERR_INVALID_ARG, "warm_max %d outside 0..64", warm_max);
+    p->dbg_mask = mask; p->dbg_warm_max = warm_max;
+    p->dbg_polish_tol = polish_tol > 0.0 ? polish_tol : 1e-11;
+    return CFS_SUCCESS;
+}
+
+int cfs_debug_stamps(cfs_problem *p, int B, unsigned long long *out)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    HIPCHK(hipSetDevice(p->device));
+    if (out) {
+        if (!p->stamps.p) return fail(CFS_ERR_INVALID_ARG, "stamps are not enabled");
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(out, p->stamps.p, (size_t)p->stamps_B * 12 * 8, hipMemcpyDeviceToHost));
+        return CFS_SUCCESS;
+    }
+    HIPCHK(hipDeviceSynchronize());
+    p->stamps.release(); p->stamps_B = 0;
+    if (B <= 0) return CFS_SUCCESS;
+    if (B > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "B=%d exceeds max_batch=%d", B, p->d.max_batch);
+    HIPCHK(p->stamps.alloc((size_t)B * 12));
+    HIPCHK(hipMemset(p->stamps.p, 0, (size_t)B * 12 * 8));
+    p->stamps_B = B;
+    return CFS_SUCCESS;
+}
+
+int cfs_debug_trace_begin(cfs_problem *p, int b, int cap)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipDeviceSynchronize());
+    p->trace.release(); p->trace_b = -1; p->trace_cap = 0;
+    if (cap <= 0) return CFS_SUCCESS;
+    HIPCHK(p->trace.alloc((size_t)(cap + 1) * 8));
+    HIPCHK(hipMemset(p->trace.p, 0, (size_t)(cap + 1) * 8 * sizeof(double)));
+    p->trace_b = b; p->trace_cap = cap;
+    return CFS_SUCCESS;
+}
+
+int cfs_debug_trace_read(cfs_problem *p, double *out)
+{
+    if (!p || !out) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    if (!p->trace.p) return fail(CFS_ERR_INVALID_ARG, "no trace was begun");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, p->trace.p, (size_t)(p->trace_cap + 1) * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return CFS_SUCCESS;
+}
+
+int cfs_debug_log_u(cfs_problem *p, int on)
+{
+    if (!p) return fail(CFS_ERR_INVALID_ARG, "NULL handle");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipDeviceSynchronize());
+    p->u_log.release();
+    if (!on || p->d.MAX_O_ITER < 1) return CFS_SUCCESS;
+    const size_t n = (size_t)p->d.max_batch * p->d.MAX_O_ITER * p->nn;
+    HIPCHK(p->u_log.alloc(n));
+    HIPCHK(hipMemset(p->u_log.p, 0, n * sizeof(double)));
+    return CFS_SUCCESS;
+}
+
+int cfs_debug_read_u_log(cfs_problem *p, int B, double *out)
+{
+    if (!p || !out) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    if (!p->u_log.p) return fail(CFS_ERR_INVALID_ARG, "the u log is not enabled");
+    if (B < 1 || B > p->d.max_batch) return fail(CFS_ERR_INVALID_ARG, "B=%d outside 1..max_batch=%d", B, p->d.max_batch);
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, p->u_log.p, (size_t)B * p->d.MAX_O_ITER * p->nn * sizeof(double), hipMemcpyDeviceToHost));
     return CFS_SUCCESS;
 }
 
@@ -1005,7 +1118,7 @@ static int linearize_piece(cfs_problem *p, int B, const PieceBuffers &pb, double
     FusedParams fp;
     fill_fused_family(p, fp, B);
     fp.x_init = pb.x_; fp.xR1 = pb.xR1; fp.ff = pb.ff; fp.caug = pb.caug; fp.obs = pb.obs;
-    fp.piece = 1; fp.no_prune = g_no_prune;
+    fp.piece = 1;
     fp.dump_dist = d_dist; fp.dump_grad = d_grad; fp.dump_linkid = d_linkid;
     if (d_linkid) HIPCHK(hipMemsetAsync(d_linkid, 0, (size_t)B * p->d.nobs * p->d.H * sizeof(int), nullptr));
     if (p->nmesh > 0) {          // rows of the mesh obstacles come from the hierarchy kernels, as in the whole solve
@@ -1017,7 +1130,7 @@ static int linearize_piece(cfs_problem *p, int B, const PieceBuffers &pb, double
         HIPCHK(launch_linearize_mesh(nj, lm, nullptr));
         fp.nmesh = p->nmesh; fp.ext_dist = p->dist.p; fp.ext_grad = p->grad.p;
     }
-    HIPCHK(launch_fused(nj, fp, nullptr));
+    HIPCHK(launch_fused(nj, fp, nullptr, force_w1(p)));
     return CFS_SUCCESS;
 }
 
@@ -1106,14 +1219,13 @@ int cfs_qp(cfs_problem *p, int B, const double *lin, const double *u_lin, const 
     fp.piece = 2;
     fp.nmesh = p->d.nobs; fp.ext_dist = d_dist; fp.ext_grad = d_grad;     // every row of the linearisation is given
     fp.u = d_u; fp.total_iter = d_it; fp.status = d_st; fp.dump_lambda = d_lam;
-    fp.dbg = g_dbg; fp.dbg_b = g_dbg_b; fp.dbg_cap = g_dbg_cap;
     if (p->d.mode == CFS_MODE_CFS) {      // start point: the unconstrained minimiser -H^{-1} ff (CFS) | u_ itself (projection)
         GemvParams g;
         g.B = B; g.nn = (int)nn; g.M = p->Hinv.p; g.X = d_lin; g.Y = p->x0.p; g.scale = -1.0;
         launch_batched_gemv(g, nullptr);
         fp.x0 = p->x0.p;
     } else fp.x0 = d_lin;
-    HIPCHK(launch_fused(p->d.njoint, fp, nullptr));
+    HIPCHK(launch_fused(p->d.njoint, fp, nullptr, force_w1(p)));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     st.down(u, d_u, (size_t)B * nn);

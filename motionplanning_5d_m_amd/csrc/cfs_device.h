@@ -112,6 +112,7 @@ struct FusedParams {
     unsigned long long *stamps;  // optional: 16 cycle accumulators per problem (developer aid)
     int opt;                     // developer A/B switches (bit 0: gather w only and roll it on the fly)
     double *u_hist;              // CFS: B x max_o_iter x nn log of u per outer iteration (cost history computed afterwards)
+    double *u_log;               // test aid (cfs_debug_log_u): the same log for either solver, no effect on the solve; may be null
     // mesh obstacles: the last nmesh of the nobs obstacles; their rows come from cfs_linearize_mesh_kernel, which needs the
     // current iterate, so the host drives such solves one outer iteration per launch and the state travels through HBM
     int nmesh;
@@ -142,7 +143,7 @@ hipError_t launch_fused_w2s(int nj, FusedParams p, hipStream_t s);
 bool fused_fits_w1(int nj, int H, int nobs);
 bool fused_fits_w2m(int nj, int H, int nobs);
 bool fused_fits_w2s(int nj, int H, int nobs);
-hipError_t launch_fused(int nj, FusedParams p, hipStream_t s);   // cfs_api.hip: tier by mode and capacity
+hipError_t launch_fused(int nj, FusedParams p, hipStream_t s, bool force_w1 = false);   // cfs_api.hip: tier by mode and capacity
 bool fused_fits(int nj, int H, int nobs);
 
 struct CostHistParams {          // EVAL.get_cost / store_result for a logged u history (CFS mode)

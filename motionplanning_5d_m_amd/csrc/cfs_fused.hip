@@ -1342,6 +1342,8 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         // logged and the whole cost history is one batched MFMA product after the solve (cfs_gemm.hip).
         // PSGCFS: QQ*u is needed in the loop (stop_inner and the next gradient step).
         double cost = cost_new;
+        if (P.u_log)                                        // test aid: the iterate of every outer iteration, either solver
+            for (int k = tid; k < HN; k += FT) P.u_log[((size_t)b * P.max_o_iter + (iter_O - 1)) * nn + k] = s_u[k];
         if (P.u_hist) {
             for (int k = tid; k < HN; k += FT) P.u_hist[((size_t)b * P.max_o_iter + (iter_O - 1)) * nn + k] = s_u[k];
             if (tid == 0) P.e_u_all[(size_t)b * P.max_o_iter + (iter_O - 1)] = sqrt(du2);

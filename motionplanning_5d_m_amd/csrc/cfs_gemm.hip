@@ -59,7 +59,7 @@ __device__ __forceinline__ double wsum(double v)
 // wavefront per problem; cost_old of iteration k is the cost of iteration k-1, caug (= get_cost(0)) for k = 0.
 __global__ __launch_bounds__(CFS_WAVE) void cfs_cost_history_kernel(CostHistParams P)
 {
-    const int b = blockIdx.x, lane = threadIdx.x, nn = P.nn, n_it = P.iter_O[b] - 1;
+    const int b = blockIdx.x, lane = threadIdx.x, nn = P.nn, n_it = P.iter_O ? P.iter_O[b] - 1 : P.max_o_iter;   // iter_O == NULL: every logged row (cfs_cost_b)
     double prev = P.caug[b];
     for (int k = 0; k < n_it; ++k) {
         const double *u = P.u_hist + ((size_t)b * P.max_o_iter + k) * nn;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(CFS_WAVE) void cfs_cost_history_kernel(CostHistPara
         const double cost = 0.5 * quad + lin + P.caug[b];
         if (lane == 0) {
             P.cost_all[(size_t)b * P.max_o_iter + k] = cost;
-            P.e_cost_all[(size_t)b * P.max_o_iter + k] = fabs(prev - cost);
+            if (P.e_cost_all) P.e_cost_all[(size_t)b * P.max_o_iter + k] = fabs(prev - cost);
         }
         prev = cost;
     }

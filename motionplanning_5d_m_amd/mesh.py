@@ -44,12 +44,21 @@ def write_stl_binary(path, tri, title="motionplanning_5d_m_amd"):
         rec.tofile(f)
 
 
-def map_from_stl(tri):
-    """Lib/functions/MapFromSTL.m:6-10: every axis shifted to start at 0, y -= 100, then (x, y, z) <- (z, x, y)."""
+def map_from_stl(tri, vmin=None):
+    """Lib/functions/MapFromSTL.m:6-10: every axis shifted to start at 0, y -= 100, then (x, y, z) <- (z, x, y).
+    vmin: the column minima to shift by (default: those of `tri`; a crop of a map passes the minima of the whole map)."""
     v = np.asarray(tri, np.float64).reshape(-1, 3).copy()
-    v -= v.min(axis=0)
+    v -= v.min(axis=0) if vmin is None else np.asarray(vmin, np.float64)
     v[:, 1] -= 100.0
     return v[:, [2, 0, 1]].reshape(-1, 3, 3)
+
+
+def load_map_fixture(path):
+    """(nt, 3, 3) float64 triangles in metres from a fixture written by tests/golden/make_reference_map.py: raw float32 STL
+    vertices of a crop of one of the reference's maps + the raw column minima of the whole file; MapFromSTL.m:6-10 and the
+    mm -> m scale are applied here in float64, exactly as cfs_mesh_load_stl(path, scale, 1) does on the file itself."""
+    d = np.load(path, allow_pickle=False)
+    return map_from_stl(d["tri_raw"].astype(np.float64), vmin=d["vmin_raw"].astype(np.float64)) * float(d["scale"])
 
 
 # ---- synthetic maps ----------------------------------------------------------------------------------

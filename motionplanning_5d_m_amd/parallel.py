@@ -69,3 +69,41 @@ def best_of(cost: torch.Tensor, status: torch.Tensor) -> int:
         return -1
     c = torch.where(ok, cost, torch.full_like(cost, float("inf")))
     return int(torch.argmin(c).item())
+
+
+def solve_sharded(solve_local, inputs: dict, B: int, group=None, keep=("u", "x_", "status", "iter_O", "cost")) -> dict:
+    """The whole multi-GPU path for a FIXED batch of B problems (strong scaling: BASELINE configs 4 and 5 are worded
+    "sharded 8 x MI355X"): every rank takes the contiguous shard `shard_bounds(B, rank, world)` of the full-batch `inputs`
+    (arrays / tensors whose leading dimension is B), solves it with `solve_local(shard_inputs, lo, hi)` on its own GPU
+    (no collective while solving), and ONE all_gather returns the full-batch results to every rank; `best` is the index of
+    the cheapest solved problem -- s_Parallel_rrt.m:16-28's `parfor` + gather + `min`.
+
+    `solve_local` returns a dict of per-problem tensors for the shard (at least the names in `keep`; `cost` = final cost).
+    On one rank (no process group) this is just the local solve.  Returns the gathered dict plus `best` and `bounds`."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    lo, hi = shard_bounds(B, rank, world)
+    shard = {k: (v[lo:hi] if v is not None else None) for k, v in inputs.items()}
+    local = solve_local(shard, lo, hi)
+    local = {k: local[k] for k in keep}
+    for k, v in local.items():
+        assert v.shape[0] == hi - lo, (k, tuple(v.shape), lo, hi)
+    full = gather_results(local, B, group=group)
+    full = dict(full)
+    full["best"] = best_of(full["cost"], full["status"])
+    full["bounds"] = (lo, hi)
+    return full
+
+
+def cfs_solve_local(slv, device, noise_key="noise"):
+    """`solve_local` for `solve_sharded` over a `solvers.CFSBatch` living on this rank's GPU: host or device inputs in,
+    device tensors out (cfs_solve_batch_device on the current stream)."""
+    def run(shard, lo, hi):
+        t = lambda a: a if isinstance(a, torch.Tensor) and a.is_cuda else torch.as_tensor(a, dtype=torch.float64).to(device).contiguous()  # noqa: E731
+        nz = shard.get(noise_key)
+        out = slv.solve_device(t(shard["x_init"]), t(shard["xR1"]), t(shard["ff"]), t(shard["caug"]), t(shard["obs"]),
+                               noise=None if nz is None else t(nz))
+        n_it = (out.iter_O - 1).clamp(min=1).long()
+        cost = out.cost_all.gather(1, (n_it - 1).unsqueeze(1)).squeeze(1)        # eval.cost_new of every problem
+        return dict(u=out.u, x_=out.x_, status=out.status, iter_O=out.iter_O, cost=cost, total_iter=out.total_iter)
+    return run

@@ -55,8 +55,10 @@ class CFSBatch:
 
     def __init__(self, sys_info, nobs, margin, mode="CFS", max_batch=1, device=None, check_dynamics=True, use_weights="auto"):
         """use_weights: True -> cfs_problem_create_from_weights(sys_info.weights) (the library assembles QQ, Qaug and alpha
-        itself: neither crosses the boundary); False -> cfs_problem_create(sys_info.QQ, ...); "auto" -> True when sys_info
-        carries the weights its matrices were assembled from (sysinfo.build_sys_info records them)."""
+        itself: neither crosses the boundary); False -> cfs_problem_create(sys_info.QQ, ...); "auto" -> the weights path, but
+        only if the QQ the library assembles from sys_info.weights IS sys_info.QQ (to 1e-12 of its largest entry; checked
+        with cfs_problem_family) and alpha agrees; a sys_info whose QQ / Baug were edited after build_sys_info is solved
+        through the dense path with the dynamics check, exactly as given."""
         s = sys_info
         self.mode = mode
         self.H, self.nj = int(s.H), int(s.njoint)
@@ -74,6 +76,8 @@ class CFSBatch:
         d.H, d.njoint, d.nobs = self.H, self.nj, self.nobs
         wts = getattr(s, "weights", None)
         self.from_weights = bool(use_weights) and wts is not None if use_weights == "auto" else bool(use_weights)
+        if use_weights == "auto" and self.from_weights and not self._double_integrator(s):
+            self.from_weights = False                    # edited Aaug / Baug: the dense path validates them (CFS_ERR_DYNAMICS)
         if self.from_weights and wts is None:
             raise ValueError("use_weights=True needs sys_info.weights")
         keep = [None if self.from_weights else np.asfortranarray(s.QQ, dtype=np.float64), _f64(s.lim),
@@ -81,6 +85,7 @@ class CFSBatch:
         d.QQ, d.lim, d.margin = _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2])
         if keep[2].size != self.nobs:
             raise ValueError("margin must have one entry per obstacle")
+        check_dynamics_asked = check_dynamics
         if self.from_weights:
             check_dynamics = False                       # Aaug / Baug are implied (and built) by the library
         if check_dynamics and getattr(s, "Aaug", None) is not None:
@@ -95,6 +100,7 @@ class CFSBatch:
         d.epsilon_O, d.MAX_O_ITER, d.alpha = float(s.epsilon_O), self.K, float(getattr(s, "alpha", 0.0))
         d.max_batch = self.max_batch
         h = C.c_void_p()
+        self._lib = lib
         if self.from_weights:
             w = _lib.cfs_cost_weights()
             keep += [np.asfortranarray(wts["Qp"], dtype=np.float64), np.asfortranarray(wts["Qv"], dtype=np.float64),
@@ -102,10 +108,45 @@ class CFSBatch:
             w.Qp, w.Qv, w.Rblk = _ptr(keep[-3]), _ptr(keep[-2]), _ptr(keep[-1])
             w.q_cross, w.w_stage, w.w_terminal, w.cR = float(wts["q_cross"]), float(wts["w_stage"]), float(wts["w_terminal"]), float(wts["cR"])
             _lib.check(lib.cfs_problem_create_from_weights(C.byref(d), C.byref(w), C.byref(h)))
+            self._h = h
+            if use_weights == "auto" and not self._weights_match(s):
+                # the caller's matrices are not the ones its weights assemble: solve what was given, through the dense path
+                self.close()
+                CFSBatch.__init__(self, sys_info, nobs, margin, mode=mode, max_batch=max_batch, device=device,
+                                  check_dynamics=check_dynamics_asked, use_weights=False)
+                return
         else:
             _lib.check(lib.cfs_problem_create(C.byref(d), C.byref(h)))
-        self._h = h
-        self._lib = lib
+            self._h = h
+
+    def _weights_match(self, s):
+        """does the QQ (and alpha) the library assembled from sys_info.weights equal what sys_info carries?"""
+        QQ = getattr(s, "QQ", None)
+        if QQ is None:
+            return True
+        QQ = np.asarray(QQ, float)
+        got, alpha = self.family()
+        if QQ.shape != got.shape or not np.abs(got - QQ).max() <= 1e-12 * np.abs(QQ).max():
+            return False
+        a = float(getattr(s, "alpha", 0.0))
+        return not (self.mode == "PSGCFS" and a != 0.0 and not abs(alpha - a) <= 1e-9 * abs(a))
+
+    def _double_integrator(self, s):
+        """is sys_info.Baug (when present) the double integrator the structured products assume (robotproperty2.m:136-139)?"""
+        Bm = getattr(s, "Baug", None)
+        if Bm is None:
+            return True
+        dt, H, nj = float(s.robot.delta_t), self.H, self.nj
+        Bm = np.asarray(Bm, float)
+        if Bm.shape != (H * 2 * nj, H * nj):
+            return False
+        Bm = Bm.reshape(H, 2 * nj, H, nj)
+        i, k = np.meshgrid(np.arange(H), np.arange(H), indexing="ij")
+        want = np.zeros_like(Bm)
+        for c in range(nj):
+            want[:, c, :, c] = np.where(k <= i, ((i - k) + 0.5) * dt * dt, 0.0)
+            want[:, nj + c, :, c] = np.where(k <= i, dt, 0.0)
+        return bool(np.abs(Bm - want).max() <= 1e-12 * (1.0 + np.abs(want).max()))
 
     def set_launch_order(self, order="auto"):
         """Workgroup w of the next solves handles problem order[w] (cfs_set_launch_order): "auto" (default: most violated
@@ -251,6 +292,65 @@ class CFSBatch:
         _lib.check(self._lib.cfs_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
+    # ---- EVAL (Lib/EVAL.m:51-53, 75-78) ------------------------------------------------------------------
+    def cost_b(self, ff, caug, want_u=False):
+        """Cost_b = get_Cost_b() for B problems: cost of the unconstrained minimiser -H^{-1} ff (cfs_cost_b)."""
+        ff, caug = _f64(np.atleast_2d(ff)), _f64(caug).reshape(-1)
+        B = ff.shape[0]
+        assert ff.shape == (B, self.nn) and caug.shape == (B,)
+        cost = np.zeros(B)
+        ub = np.zeros((B, self.nn)) if want_u else None
+        _lib.check(self._lib.cfs_cost_b(self._h, B, _ptr(ff), _ptr(caug), _ptr(cost), _ptr(ub)))
+        return (cost, ub) if want_u else cost
+
+    def get_cost(self, u, ff, caug):
+        """get_cost(u) = 0.5 u'QQ u + ff'u + caug for B given u (cfs_get_cost)."""
+        u, ff, caug = _f64(np.atleast_2d(u)), _f64(np.atleast_2d(ff)), _f64(caug).reshape(-1)
+        B = u.shape[0]
+        assert u.shape == (B, self.nn) and ff.shape == (B, self.nn) and caug.shape == (B,)
+        cost = np.zeros(B)
+        _lib.check(self._lib.cfs_get_cost(self._h, B, _ptr(u), _ptr(ff), _ptr(caug), _ptr(cost)))
+        return cost
+
+    # ---- developer / test switches (cfs_debug_*, per handle) ---------------------------------------------
+    def debug_options(self, warm_max=0, polish_tol=0.0, **flags):
+        """cfs_debug_set_options: flags from _lib.DBG (gather_rollouts, no_refine, no_warm_start, no_certificate, no_prune,
+        no_auto_order, tier_w1); no flags = the defaults."""
+        mask = 0
+        for k, v in flags.items():
+            if v:
+                mask |= _lib.DBG[k]
+        _lib.check(self._lib.cfs_debug_set_options(self._h, mask, int(warm_max), float(polish_tol)))
+
+    def stamps(self, B=None):
+        """B given: enable the cycle stamps for the next solves of <= B problems (0: off); B None: read them, (n, 12) uint64."""
+        if B is not None:
+            _lib.check(self._lib.cfs_debug_stamps(self._h, int(B), None))
+            self._stamps_B = int(B)
+            return None
+        out = np.zeros((self._stamps_B, 12), np.uint64)
+        _lib.check(self._lib.cfs_debug_stamps(self._h, self._stamps_B, _ptr(out)))
+        return out
+
+    def trace(self, b=None, cap=0):
+        """b given: trace the active-set steps of problem b (cap records; cap 0: off); b None: read, (n, 8) float64."""
+        if b is not None:
+            _lib.check(self._lib.cfs_debug_trace_begin(self._h, int(b), int(cap)))
+            self._trace_cap = int(cap)
+            return None
+        buf = np.zeros((self._trace_cap + 1) * 8)
+        _lib.check(self._lib.cfs_debug_trace_read(self._h, _ptr(buf)))
+        return buf[8:8 + 8 * int(buf[0])].reshape(-1, 8)
+
+    def log_u(self, on=True):
+        """log u after every outer iteration of the next solves (either solver; cfs_debug_log_u)."""
+        _lib.check(self._lib.cfs_debug_log_u(self._h, 1 if on else 0))
+
+    def read_u_log(self, B):
+        out = np.zeros((B, self.K, self.nn))
+        _lib.check(self._lib.cfs_debug_read_u_log(self._h, int(B), _ptr(out)))
+        return out
+
     # ---- pieces -----------------------------------------------------------------------------------
     def linearize(self, x_, obs):
         x_, obs = _f64(x_), _f64(obs)
@@ -295,14 +395,59 @@ def dist_arm(robot, theta, obs_l, want_pos=False):
 
 
 class EVAL:
-    """Result holder with the reference's field names (Lib/EVAL.m:9-37)."""
+    """Lib/EVAL.m: ``eval = EVAL(sys_info)``, ``Cost_b = eval.get_Cost_b()`` (main_FANUC.m:131-132), ``get_cost(u)``,
+    ``store_result(u)``, ``stop_outer(iter_O)`` with the reference's field names (:9-37).  The two cost functions run in
+    libcfs_hip.so (cfs_cost_b, cfs_get_cost: QQ*u on the matrix cores); the stop test and the history appends are the
+    reference's host-side bookkeeping.  Inside ``optimizer()`` all of this happens in the fused kernel; the methods are for
+    callers that use EVAL on its own, as main_FANUC.m does for the baseline cost."""
 
-    def __init__(self, sys_info):
+    def __init__(self, sys_info, device=None):
         self.sys_info = sys_info
-        self.epsilon_O, self.MAX_O_ITER = sys_info.epsilon_O, sys_info.MAX_O_ITER
-        self.x_ = np.asarray(sys_info.x_, float).copy()
+        self.epsilon_O, self.MAX_O_ITER = sys_info.epsilon_O, sys_info.MAX_O_ITER     # EVAL.m:43-44
+        self.x_ = np.asarray(sys_info.x_, float).reshape(-1).copy()                   # :46
+        self.x_old = np.ones_like(self.x_)                                            # :47
+        self.u_old = None
+        self.Cost_b = 0.0
+        self.total_iter = 0
+        self.cost_old, self.cost_new = 100000.0, 0.0                                  # :29-30
         self.cost_all, self.e_cost_all, self.e_u_all = np.zeros(0), np.zeros(0), np.zeros(0)
-        self.cost_new = 0.0
+        self._device, self._batch = device, None
+
+    def _family(self):
+        if self._batch is None:      # the family handle (QQ and its inverse on the device); obstacles play no role in the costs
+            self._batch = CFSBatch(self.sys_info, 1, [0.0], mode="CFS", max_batch=1, device=self._device)
+        return self._batch
+
+    def get_cost(self, u):
+        """cost = 0.5*u'*Qaug*u + paug'*u + caug with the drivers' Qaug = QQ, paug = ff (EVAL.m:51-53, main_FANUC.m:110-112)."""
+        s = self.sys_info
+        return float(self._family().get_cost(np.asarray(u, float).reshape(1, -1), _f64(s.ff).reshape(1, -1), np.array([s.caug], float))[0])
+
+    def get_Cost_b(self):
+        """cost of the unconstrained QP's minimiser (EVAL.m:75-78)."""
+        s = self.sys_info
+        self.Cost_b = float(self._family().cost_b(_f64(s.ff).reshape(1, -1), np.array([s.caug], float))[0])
+        return self.Cost_b
+
+    def store_result(self, u):
+        """EVAL.m:55-59."""
+        u = np.asarray(u, float).reshape(-1)
+        u_old = np.zeros_like(u) if self.u_old is None else np.asarray(self.u_old, float).reshape(-1)
+        self.cost_all = np.append(self.cost_all, self.cost_new)
+        self.e_cost_all = np.append(self.e_cost_all, abs(self.cost_old - self.cost_new))
+        self.e_u_all = np.append(self.e_u_all, float(np.linalg.norm(u_old - u)))
+        return self
+
+    def stop_outer(self, iter_O):
+        """EVAL.m:61-73: stop when ||x_ - x_old|| < epsilon_O or iter_O > MAX_O_ITER."""
+        stop = False
+        if float(np.linalg.norm(np.asarray(self.x_, float).reshape(-1) - np.asarray(self.x_old, float).reshape(-1))) < self.epsilon_O:
+            print(f"Converged at step{iter_O}")
+            stop = True
+        if iter_O > self.MAX_O_ITER:
+            print("MAX_ITER")
+            stop = True
+        return stop
 
 
 class _SolverBase:

@@ -101,7 +101,7 @@ def config4(route_wp, B=4096, seed=20260104, H=40, sigma=0.02):
     return s, batch
 
 
-def config5(B=256, seed=20260105, H=50, n_tri=10000, margin=0.12):
+def config5(B=256, seed=20260105, H=50, n_tri=10000, margin=0.12, tri=None):
     """BASELINE config 5 (mesh map, 50 waypoints, 256 seeds), synthetic: the reference's assembly-line map is an STL
     file that cannot travel (map/assembly line_Assem1.STL, 27 396 triangles, mm) and its distance function is missing
     from the reference, so the map is ``mesh.assembly_line`` (about n_tri triangles, metres, around the M200i base) and
@@ -113,7 +113,26 @@ def config5(B=256, seed=20260105, H=50, n_tri=10000, margin=0.12):
     xg = X0C * np.array([-1.0, 1, 1, 1, 1]) + rng.uniform(-0.1, 0.1, (B, 5))
     noise = 0.1 * rng.standard_normal((B, 20, H * 5))
     x_init, xR1, ff, caug = _batch_terms(s, x0, xg)
-    tri = assembly_line(s.robot.base, n_target=n_tri, seed=seed)
+    if tri is None:
+        tri = assembly_line(s.robot.base, n_target=n_tri, seed=seed)
     batch = SimpleNamespace(B=B, nobs=1, x0=x0, xg=xg, x_init=x_init, xR1=xR1, ff=ff, caug=caug, obs=np.zeros((B, 1, 6)),
                             noise=noise, margin_cfs=np.full(1, margin), margin_psg=np.full(1, margin))
+    return s, batch, tri
+
+
+def config5_reference_map(B=256, seed=20260105, H=50, fixture=None):
+    """BASELINE config 5 on the REFERENCE's own triangles: the cell of map/assembly line_Assem1.STL around robot.base after
+    Lib/functions/MapFromSTL.m:6-10 and mm -> m (tests/golden/assembly_line_cell.npz, a data fixture made in the build
+    container by tests/golden/make_reference_map.py: 13 258 of the file's 27 396 triangles, every one with a vertex within
+    2.5 m of the base).  Same start / goal draws, horizon and noise as `config5`; margins are main_FANUC.m:59-60's own
+    (D = 0.2 for PSGCFS_FANUC, epsilon = 0.25 for CFS_FANUC): the joint-space line between start and goal passes the
+    assembly line at 0.17-0.21 m, so every problem has active collision rows and (oracle, first 16) all are feasible.  The
+    distance function is still the build's own (the reference calls an undefined point2surface_dis): parity unpinned,
+    see DESIGN.md section 9."""
+    import os
+    from .mesh import load_map_fixture
+    if fixture is None:
+        fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assembly_line_cell.npz")
+    s, batch, tri = config5(B=B, seed=seed, H=H, tri=load_map_fixture(fixture))
+    batch.margin_cfs, batch.margin_psg = np.full(1, 0.25), np.full(1, 0.2)
     return s, batch, tri

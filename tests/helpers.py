@@ -95,3 +95,37 @@ def chaotic_problems(O, s, bt, mode, w0, K=None, reps=3, kick=1e-12, move=1e-6, 
         mv = np.maximum(mv, np.abs(w1.x_ - w0.x_).max(axis=1))
         flip |= (w1.status != w0.status) | (w1.iter_O != w0.iter_O)
     return (mv > move) | flip, mv
+
+
+def oracle_obs(bt, b, margin):
+    """obs cell of problem b in the oracle's form"""
+    return [dict(l=np.stack([bt.obs[b, j, :3], bt.obs[b, j, 3:]], axis=1), epsilon=margin[j], D=margin[j]) for j in range(bt.obs.shape[1])]
+
+
+def oracle_one_step(O, s, bt, mode, b, k, u_prev, margin, noise_row=None, robot_name="M200i"):
+    """ONE outer iteration of the ORACLE (get_con + QP of Lib/CFS_FANUC.m:66-72 | the PSG step + projection of
+    Lib/PSGCFS_FANUC.m:86-103), number k (= iter_O, 1-based), started from a GIVEN iterate u_prev (the u after iteration
+    k-1; ignored for k = 1, where u = 0 and x_ = x_init as the constructors leave them).  Returns (u_k, status) with status
+    0 = solved, otherwise the oracle's QP failed (2 = infeasible).  This is what makes iterations >= 2 of a chaotic problem
+    checkable: the device's own previous iterate is the starting point, so only ONE iteration's amplification is in play."""
+    from types import SimpleNamespace
+    H, nj = s.H, 5
+    nn = H * nj
+    s2 = SimpleNamespace(**vars(s))
+    s2.xR1, s2.robot = bt.xR1[b], O.robotproperty2(robot_name)
+    if k == 1:
+        u, x_ = np.zeros(nn), bt.x_init[b]
+    else:
+        u = np.asarray(u_prev, float)
+        x_ = O.rollout(H, nj, s.robot.delta_t, bt.xR1[b], u)
+    A, rhs, *_ = O.get_con(robot_name, s2, oracle_obs(bt, b, margin), x_, u, mode=mode)
+    if mode == "CFS":
+        G, g0 = s.QQ, bt.ff[b]
+        A = np.vstack([A, np.eye(nn), -np.eye(nn)])
+        rhs = np.concatenate([rhs, s.MAX_input, s.MAX_input])
+    else:
+        nz = np.zeros(nn) if noise_row is None else noise_row
+        u_ = u - s.alpha * ((s.QQ @ u + bt.ff[b]) + 10.0 * nz / (float(k) * float(k) + 1.0))     # PSGCFS_FANUC.m:109
+        G, g0 = np.eye(nn), -u_
+    x, _, _, st, _ = O.qp_solve(G, g0, A, rhs)
+    return x, st

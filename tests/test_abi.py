@@ -45,9 +45,10 @@ def test_argument_validation_and_no_device_error():
     import copy
     s2 = copy.copy(s); s2.Baug = s.Baug.copy(); s2.Baug[3, 0] += 1e-3
     if pkg.device_count() == 0:
-        with pytest.raises(pkg.CfsError) as e:
-            pkg.CFSBatch(s2, 1, [0.25], use_weights=False)
-        assert e.value.code == -5                      # CFS_ERR_DYNAMICS is detected before touching the device
+        for uw in (False, "auto"):                     # "auto" does not trust the weights when Baug was edited: dense path, validated
+            with pytest.raises(pkg.CfsError) as e:
+                pkg.CFSBatch(s2, 1, [0.25], use_weights=uw)
+            assert e.value.code == -5                  # CFS_ERR_DYNAMICS is detected before touching the device
         with pytest.raises(pkg.CfsError) as e:
             pkg.CFS_FANUC(obs, s, R)
         assert e.value.code == -2                      # CFS_ERR_NO_DEVICE: nothing falls back to the CPU

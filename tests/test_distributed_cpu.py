@@ -42,6 +42,14 @@ def _worker(rank, world, B, port, q):
         ok = (torch.equal(full["x_"], x_init * 2 + 1) and torch.equal(full["cost"], x_init.sum(dim=1))
               and torch.equal(full["status"], (x_init[:, 0] > 0).to(torch.int32))
               and torch.equal(full["iter_O"], torch.arange(B, dtype=torch.int32)))
+        # the whole sharded path (shard -> local solve -> one gather -> best seed) through solve_sharded, same stand-in solve
+        def solve_local(shard, lo_, hi_):
+            m = shard["x_init"]
+            return dict(u=m * 3, x_=m * 2 + 1, cost=m.sum(dim=1), status=(m[:, 0] > 0).to(torch.int32),
+                        iter_O=torch.arange(lo_, hi_, dtype=torch.int32))
+        sh = parallel.solve_sharded(solve_local, dict(x_init=x_init, noise=None), B)
+        ok = ok and torch.equal(sh["x_"], full["x_"]) and torch.equal(sh["u"], x_init * 3) and sh["bounds"] == (lo, hi) \
+            and sh["best"] == parallel.best_of(full["cost"], full["status"])
         q.put((rank, bool(ok), parallel.best_of(full["cost"], full["status"])))
     finally:
         dist.destroy_process_group()

@@ -74,7 +74,7 @@ def test_five_joints_h50_line_obstacles_through_the_256_row_instantiation(gpu, O
     # nn = 250 > 160: cfs_solve_fused_kernel<5, 256, .>; main_FANUC.m's obstacle and a second, farther one; both solvers, a small batch against the oracle
     robot, orobot = gpu.robotproperty2("M200i"), O.robotproperty2("M200i")
     x0 = np.array([0.7825, 0.0284, 0.2172, 0.1444, -1.1779])
-    H, B = 50, 8
+    H, B = 50, 64
     rng = np.random.default_rng(50)
     kw = dict(Qp=np.diag([10.0, 10, 1, 1, 1]), Qv=np.diag([10.0, 10, 1, 1, 1]), Rblk=np.eye(5) * 2, cR=50.0, lim=np.ones(5),
               max_input_blk=np.array([1, 1, np.pi, np.pi, np.pi]) * robot.delta_t, epsilon_O=0.1, MAX_O_ITER=20)
@@ -100,10 +100,12 @@ def test_five_joints_h50_line_obstacles_through_the_256_row_instantiation(gpu, O
                                  margin, s0.epsilon_O, s0.MAX_O_ITER, s0.alpha, noise=noise, nthreads=0)
         chaotic, moved_by = chaotic_problems(O, s0, bt, mode, want)       # H = 50: a longer, stiffer iteration (see test_gpu_batch.py)
         same = (got.status == want.status) & (got.iter_O == want.iter_O)
-        # PSGCFS never stops early: 20 forced iterations at H = 50 leave most of these problems beyond what the oracle itself pins
-        assert same[~chaotic].all() and chaotic.sum() <= (B // 2 if mode == "CFS" else 3 * B // 4), (mode, chaotic)
+        # PSGCFS never stops early: 20 forced iterations at H = 50 leave many of these problems beyond what the oracle itself pins;
+        # at least 16 of the 64 must be pinned AND solved, and every one of those must agree
+        print(f"[H=50 line obstacles {mode}] chaotic {int(chaotic.sum())} of {B}: {np.nonzero(chaotic)[0].tolist()}")
+        assert same[~chaotic].all(), (mode, np.nonzero(~same & ~chaotic)[0])
         ok = same & (want.status < 2) & ~chaotic
-        assert ok.sum() >= 2
+        assert ok.sum() >= 16, (mode, int(ok.sum()), int(chaotic.sum()))
         err = np.abs(got.x_ - want.x_).max(axis=1)
         assert err[ok].max() < 1e-5, (mode, err, moved_by)
 
@@ -127,7 +129,58 @@ def test_config4_4096_routes(gpu, O, route_wp):
     idx = np.arange(0, B, B // 64)
     w = O.optimizer_batch(O.robotproperty2("M200i"), "CFS", H, 5, bt.x_init[idx], bt.xR1[idx], s.QQ, bt.ff[idx], bt.caug[idx], s.Aaug, s.Baug,
                           s.lim, s.MAX_input, bt.obs[idx], bt.margin_cfs, s.epsilon_O, s.MAX_O_ITER, s.alpha, nthreads=0)
+    from types import SimpleNamespace
+    from helpers import chaotic_problems
+    sub = SimpleNamespace(x_init=bt.x_init[idx], xR1=bt.xR1[idx], ff=bt.ff[idx], caug=bt.caug[idx], obs=bt.obs[idx], noise=None,
+                          margin_cfs=bt.margin_cfs, margin_psg=bt.margin_psg)
+    chaotic, moved_by = chaotic_problems(O, s, sub, "CFS", w)       # decided by the oracle alone (helpers.py)
+    print(f"[config4 4096] sample of {idx.size}: chaotic {np.nonzero(chaotic)[0].tolist()}")
+    assert chaotic.sum() <= 0.15 * idx.size
     same = (got.status[idx] == w.status) & (got.iter_O[idx] == w.iter_O)
-    assert same.mean() >= 0.95, np.nonzero(~same)[0]
-    ok = same & (w.status < 2)
-    assert np.median(np.abs(got.x_[idx] - w.x_).max(axis=1)[ok]) < 1e-6
+    assert same[~chaotic].all(), np.nonzero(~same & ~chaotic)[0]
+    ok = same & (w.status < 2) & ~chaotic
+    err = np.abs(got.x_[idx] - w.x_).max(axis=1)
+    assert ok.sum() >= 0.6 * idx.size and err[ok].max() < 1e-5, (int(ok.sum()), err[ok].max())
+    assert np.median(err[ok]) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["PSGCFS", "CFS"])
+def test_config5_on_the_reference_map(gpu, O, mode):
+    """BASELINE config 5 on the reference's OWN triangles: the cell of map/assembly line_Assem1.STL around robot.base after
+    Lib/functions/MapFromSTL.m:6-10 and mm -> m (tests/golden/assembly_line_cell.npz: 13 258 triangles, data only; made by
+    tests/golden/make_reference_map.py in the build container), H = 50, 256 seeds, the margins of main_FANUC.m:59-60.
+    The oracle (brute force over every triangle) on the first problems, size-independent properties on all 256."""
+    B, H = 256, 50
+    ncheck = 4 if mode == "PSGCFS" else 6                          # ~7 s (PSGCFS, 20 iterations) / ~1.5 s (CFS) of oracle per problem and core
+    s, bt, tri = workloads.config5_reference_map(B=B)
+    assert tri.shape == (13258, 3, 3) and s.H == H
+    bb = tri.reshape(-1, 3)
+    assert bb[:, 2].min() == 0.0 and np.all(bb.min(axis=0) < s.robot.base) and np.all(s.robot.base < bb.max(axis=0))   # the robot stands inside its cell
+    mesh = gpu.Mesh(tri=tri)
+    margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
+    slv = gpu.CFSBatch(s, 1, margin, mode=mode, max_batch=B)
+    slv.set_meshes([mesh])
+    noise = bt.noise if mode == "PSGCFS" else None
+    got = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs, noise=noise)
+    x, moved = _properties(O, s, bt, got, H, bounds=s.MAX_input if mode == "CFS" else None)
+    done = got.status == 0 if mode == "CFS" else (got.status == 1)
+    assert done.sum() > 0.8 * B, np.bincount(got.status, minlength=4)
+    assert got.total_iter[done].mean() >= 3                        # the map is in the way: the QPs have active collision rows
+    th = x[done][:, :, :5].reshape(-1, 5)
+    d = gpu.dist_arm_surf(s.robot, th, mesh)[0].reshape(done.sum(), H)
+    assert d.min() > margin[0] - 2e-2, d.min()                     # one linearisation old: the stop tolerance allows a few mm
+    # the same map through the STL entry point gives the same distances (cfs_mesh_load_stl's transform == the fixture loader's)
+    l = O.mesh_register(0, tri)
+    oobs = np.tile(np.concatenate([l[:, 0], l[:, 1]]), (ncheck, 1, 1))
+    w = O.optimizer_batch(O.robotproperty2("M200i"), mode, H, 5, bt.x_init[:ncheck], bt.xR1[:ncheck], s.QQ, bt.ff[:ncheck], bt.caug[:ncheck],
+                          s.Aaug, s.Baug, s.lim, s.MAX_input, oobs, margin, s.epsilon_O, s.MAX_O_ITER, s.alpha,
+                          noise=None if noise is None else noise[:ncheck])
+    np.testing.assert_array_equal(got.status[:ncheck], w.status)
+    np.testing.assert_array_equal(got.iter_O[:ncheck], w.iter_O)
+    ok = w.status < 2
+    err = np.abs(got.x_[:ncheck][ok] - w.x_[ok]).max()
+    print(f"[config5 reference map {mode}] status {np.bincount(got.status, minlength=4).tolist()}, mean active-set steps {got.total_iter.mean():.1f}, "
+          f"l_inf vs oracle on {int(ok.sum())} problems {err:.1e} rad")
+    assert ok.sum() >= 3 and err < 1e-5                            # the north-star bar (faceted surface: DESIGN.md section 9)
+    slv.close()
+    mesh.close()

@@ -61,14 +61,12 @@ def test_first_outer_iteration_of_the_fused_kernel(gpu, O, route_wp, tag, mode):
     slv = gpu.CFSBatch(s1, nobs, margin, mode=mode, max_batch=B)
 
     # ---- linearisation piece of the fused kernel: pruned == unpruned bit for bit, and == oracle --------------------
-    lib = gpu.lib()
     dist, lid, grad = slv.linearize(bt.x_init, bt.obs)
-    lib.cfs_debug_no_prune.argtypes, lib.cfs_debug_no_prune.restype = [C.c_int], C.c_int
-    lib.cfs_debug_no_prune(1)
+    slv.debug_options(no_prune=True)                    # cfs_debug_set_options, per handle
     try:
         dist_u, lid_u, grad_u = slv.linearize(bt.x_init, bt.obs)
     finally:
-        lib.cfs_debug_no_prune(0)
+        slv.debug_options()
     np.testing.assert_array_equal(dist, dist_u)
     np.testing.assert_array_equal(grad, grad_u)
     np.testing.assert_array_equal(lid, lid_u)

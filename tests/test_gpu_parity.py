@@ -300,3 +300,40 @@ def test_two_link_arm_long_horizon(gpu, O):
     want = O.optimizer("2L", t, [dict(l=ob[0]["l"], D=0.05, epsilon=0.05)], "CFS")
     assert got.status == want.status and got.iter_O == want.iter_O
     assert np.abs(got.x_ - want.x_).max() < 1e-6
+
+
+def test_eval_get_cost_b_and_get_cost(gpu, O, route_wp):
+    """EVAL.get_Cost_b (Lib/EVAL.m:75-78, called at main_FANUC.m:131-132) and get_cost (:51-53) through cfs_cost_b / cfs_get_cost
+    against the oracle's unconstrained QP.  Tolerance: 1e-10 relative on the cost (two fp64 MFMA products against a Cholesky
+    solve; cond(QQ) = 6e5 .. 1.7e8)."""
+    for name, (R, s, obs), P in (("main_FANUC", gpu.main_FANUC_problem(), O.problem_main_FANUC()),
+                                  ("RRTstar_CFS", gpu.RRTstar_CFS_problem(route_wp), O.problem_RRTstar_CFS(route_wp)),
+                                  ("main_2L", gpu.main_2L_problem(), O.problem_main_2L())):
+        so = P.sys_info
+        nn = s.H * s.nu
+        ub, _, _, st, _ = O.qp_solve(so.QQ, so.ff, np.zeros((0, nn)), np.zeros(0))          # quadprog(Qaug, paug) without constraints
+        assert st == 0
+        want = 0.5 * ub @ so.QQ @ ub + so.ff @ ub + so.caug
+        ev = gpu.EVAL(s)
+        cost_b = ev.get_Cost_b()
+        assert abs(cost_b - want) <= 1e-10 * max(abs(want), abs(so.caug)), (name, cost_b, want)
+        assert ev.Cost_b == cost_b
+        u = np.random.default_rng(3).standard_normal(nn) * 0.01
+        want_u = 0.5 * u @ so.QQ @ u + so.ff @ u + so.caug
+        assert abs(ev.get_cost(u) - want_u) <= 1e-12 * max(abs(want_u), abs(so.caug)), name
+        assert abs(ev.get_cost(np.zeros(nn)) - so.caug) <= 1e-15 * abs(so.caug)             # get_cost(zeros) = caug
+    # batched, from a handle of either mode, with the minimiser returned
+    R, s, obs = gpu.main_FANUC_problem()
+    rng = np.random.default_rng(4)
+    ff = s.ff[None] * (1.0 + 0.1 * rng.standard_normal((7, 1)))
+    caug = np.full(7, s.caug)
+    for mode in ("CFS", "PSGCFS"):
+        slv = gpu.CFSBatch(s, 1, [0.2], mode=mode, max_batch=7)
+        cb, ub = slv.cost_b(ff, caug, want_u=True)
+        H = 0.5 * (s.QQ + s.QQ.T)
+        for b in range(7):
+            wu = -np.linalg.solve(H, ff[b])
+            assert np.abs(ub[b] - wu).max() <= 1e-9 * np.abs(wu).max()
+            wc = 0.5 * wu @ s.QQ @ wu + ff[b] @ wu + caug[b]
+            assert abs(cb[b] - wc) <= 1e-10 * abs(caug[b])
+        slv.close()

@@ -95,3 +95,21 @@ def test_config5_workload_shapes_and_determinism():
     base = s.robot.base
     v = tri.reshape(-1, 3)
     assert v[:, 0].min() > base[0] + 0.4 and np.isfinite(v).all()      # the map stands in front of the arm, clear of its base
+
+
+def test_eval_host_bookkeeping_follows_the_reference():
+    """EVAL.stop_outer / store_result (Lib/EVAL.m:55-73) are host-side bookkeeping in the reference too: the constructor
+    state (x_old = ones :47, cost_old = 100000 :29), the two stop conditions and the history appends."""
+    import motionplanning_5d_m_amd as pkg
+    R, s, obs = pkg.main_FANUC_problem()
+    ev = pkg.EVAL(s)
+    assert ev.cost_old == 100000.0 and ev.cost_new == 0.0 and ev.Cost_b == 0.0 and np.all(ev.x_old == 1.0)
+    assert ev.x_.shape == (s.H * s.nstate,) and ev.MAX_O_ITER == s.MAX_O_ITER and ev.epsilon_O == s.epsilon_O
+    assert not ev.stop_outer(1)                       # ||x_ - ones|| is far above epsilon_O and iter_O <= MAX_O_ITER
+    assert ev.stop_outer(s.MAX_O_ITER + 1)            # "MAX_ITER"
+    ev.x_old = ev.x_ + 0.5 * s.epsilon_O / np.sqrt(ev.x_.size)
+    assert ev.stop_outer(3)                           # "Converged at step3"
+    ev.u_old, ev.cost_new = np.zeros(s.H * s.nu), 5.0
+    ev.store_result(np.full(s.H * s.nu, 2.0))
+    assert ev.cost_all.tolist() == [5.0] and ev.e_cost_all.tolist() == [abs(100000.0 - 5.0)]
+    assert abs(ev.e_u_all[0] - 2.0 * np.sqrt(s.H * s.nu)) < 1e-12

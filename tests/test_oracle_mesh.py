@@ -128,3 +128,27 @@ def test_reference_stl_maps_parse_and_measure(O):
         good = np.linalg.norm(nrm, axis=1) > 1e-12
         off = np.abs(np.einsum("ij,ij->i", nrm[good], pts[good][:, 3:] - on[good][:, 0])) / np.linalg.norm(nrm[good], axis=1)
         assert off.max() < 1e-9
+
+
+def test_reference_map_fixture_is_the_reference_file(O):
+    """tests/golden/assembly_line_cell.npz holds DATA of /root/reference/map/assembly line_Assem1.STL: where the reference is
+    present (the build container) the fixture loader must reproduce, bit for bit, the triangles the package's STL reader +
+    MapFromSTL.m:6-10 + mm -> m give for the whole file, cropped to 2.5 m around robot.base."""
+    import os
+    from motionplanning_5d_m_amd import mesh
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tri = mesh.load_map_fixture(os.path.join(root, "tests", "golden", "assembly_line_cell.npz"))
+    assert tri.shape == (13258, 3, 3)
+    src = "/root/reference/map/assembly line_Assem1.STL"
+    if not os.path.exists(src):
+        pytest.skip("the reference is not present on this box")
+    full = mesh.map_from_stl(mesh.read_stl_binary(src)) * 1e-3
+    base = np.array([3.150, 8.500, 0.330])
+    keep = np.linalg.norm(full - base, axis=2).min(axis=1) < 2.5
+    assert full.shape[0] == 27396
+    np.testing.assert_array_equal(full[keep], tri)
+    # the reference's own transformed copy of the same map (map/environment.mat: envir.v in mm, MapFromSTL's output) agrees
+    import scipy.io
+    env = scipy.io.loadmat("/root/reference/map/environment.mat")["envir"]["v"][0, 0]
+    assert env.shape == (27396 * 3, 3)
+    np.testing.assert_allclose(env.reshape(-1, 3, 3) * 1e-3, full, rtol=0, atol=1e-9)

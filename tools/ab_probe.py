@@ -1,5 +1,7 @@
-"""Developer A/B probe: solve config 3 in both modes with the library named by CFS_LIBNAME, save the results and
-timings; `python tools/ab_probe.py cmp a.npz b.npz` reports bitwise equality.  Run each variant in its own process."""
+"""Developer A/B probe: `python tools/ab_probe.py out.npz [libname.so] [flag ...]` solves config 3 in both modes with the given
+build of the library (default libcfs_hip.so, a file next to it) and the given cfs_debug_set_options flags (names of _lib.DBG,
+`warm_max=N`), saves results and timings; `python tools/ab_probe.py cmp a.npz b.npz` reports bitwise equality.  Run each
+variant in its own process."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,6 +16,11 @@ if sys.argv[1] == "cmp":
     sys.exit(0)
 
 import torch
+from motionplanning_5d_m_amd import _lib
+LIBNAME = next((a for a in sys.argv[2:] if a.endswith(".so")), "libcfs_hip.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), LIBNAME)          # before the first lib() call
+FLAGS = {a: True for a in sys.argv[2:] if a in _lib.DBG}
+WARM = next((int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("warm_max=")), 0)
 import motionplanning_5d_m_amd as pkg
 from motionplanning_5d_m_amd import workloads
 B = 1024
@@ -25,6 +32,8 @@ for mode in ("CFS", "PSGCFS"):
     margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
     S = 8
     slvs = [pkg.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=B) for _ in range(S)]
+    for sl in slvs:
+        sl.debug_options(warm_max=WARM, **FLAGS)
     x_init, xR1, ff, caug, obs = t(bt.x_init), t(bt.xR1), t(bt.ff), t(bt.caug), t(bt.obs)
     noise = t(bt.noise) if mode == "PSGCFS" else None
     outs = [sl.alloc_outputs(B, dev) for sl in slvs]
@@ -46,7 +55,7 @@ for mode in ("CFS", "PSGCFS"):
         dt = min(dt, (time.perf_counter() - t0) / n)
     o = outs[0]
     its = int((o.iter_O - 1).sum().item())
-    print(f"{os.environ.get('CFS_LIBNAME', 'libcfs_hip.so')} {mode}: single {lat*1e3:.2f} ms, overlapped {dt*1e3:.3f} ms/solve, {its/dt:.3e} it/s, "
+    print(f"{LIBNAME} {sorted(FLAGS)} warm_max={WARM} {mode}: single {lat*1e3:.2f} ms, overlapped {dt*1e3:.3f} ms/solve, {its/dt:.3e} it/s, "
           f"status {np.bincount(o.status.cpu().numpy(), minlength=4).tolist()}", flush=True)
     for k in ("u", "x_", "status", "iter_O", "total_iter", "cost_all"):
         res[f"{mode}_{k}"] = getattr(o, k).cpu().numpy()

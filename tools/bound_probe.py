@@ -11,10 +11,9 @@ inf = np.nonzero((full.status == 2) & (full.iter_O == 1))[0][:24]
 one = pkg.CFSBatch(s, bt.nobs, bt.margin_cfs, mode="CFS", max_batch=1)
 lib = _lib.lib(); cap = 1500
 for b in inf:
-    lib.cfs_debug_trace_begin(0, cap)
+    one.trace(0, cap)
     sl = slice(b, b + 1)
     r = one.solve(bt.x_init[sl], bt.xR1[sl], bt.ff[sl], bt.caug[sl], bt.obs[sl])
-    buf = np.zeros((cap + 1) * 8); lib.cfs_debug_trace_read(buf.ctypes.data_as(C.c_void_p))
-    n = int(buf[0]); rec = buf[8:8 + n * 8].reshape(n, 8); ratio = rec[:, 7]
+    rec = one.trace(); n = rec.shape[0]; ratio = rec[:, 7]
     cross = [int(np.argmax(ratio > th)) if (ratio > th).any() else -1 for th in (1e-8, 1e-6, 1e-4, 1e-2, 1e-1)]
     print(f"problem {b}: steps {n}, first step with fgain/fbound > 1e-8,1e-6,1e-4,1e-2,1e-1: {cross}, final ratio {ratio[-1]:.2e}, q_end {int(rec[-1,1])}")

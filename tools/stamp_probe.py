@@ -10,11 +10,9 @@ margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
 slv = pkg.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=B)
 lib = _lib.lib()
 r = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs, noise=bt.noise if mode != "CFS" else None)   # warm
-lib.cfs_debug_stamps(B, None)
+slv.stamps(B)
 r = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs, noise=bt.noise if mode != "CFS" else None)
-st = np.zeros((B, 12), np.uint64)
-lib.cfs_debug_stamps(B, st.ctypes.data_as(C.c_void_p))
-st = st.astype(np.float64)
+st = slv.stamps().astype(np.float64)
 names = ["lin: base dist+minima+FD", "qp setup", "step1 scan", "w gather+roll", "d, r=Pd", "z+roll+refine", "steplen/update", "add", "drop", "post (roll,cost)", "lin: sincos+FK", "lin: shifted pairs"]
 tot = st.sum(axis=1)
 its = r.iter_O - 1; steps = r.total_iter

@@ -11,11 +11,9 @@ s, bt = workloads.config4(route, B=B)
 slv = pkg.CFSBatch(s, bt.nobs, bt.margin_cfs, mode="CFS", max_batch=B)
 lib = _lib.lib()
 r = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs)
-lib.cfs_debug_stamps(B, None)
+slv.stamps(B)
 r = slv.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs)
-st = np.zeros((B, 12), np.uint64)
-lib.cfs_debug_stamps(B, st.ctypes.data_as(C.c_void_p))
-st = st.astype(np.float64)
+st = slv.stamps().astype(np.float64)
 names = ["lin: base dist+minima+FD", "qp setup", "step1 scan", "w gather+roll", "d, r=Pd", "z+roll+refine", "steplen/update", "add", "drop", "post (roll,cost)", "lin: sincos+FK", "lin: shifted pairs"]
 TICK = 1.0 / 21.0
 its = r.iter_O - 1; steps = r.total_iter

@@ -9,12 +9,10 @@ s, bt = workloads.config3(lambda rb, th, ob: pkg.dist_arm(rb, th, ob)[0], B=B)
 margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
 slv = pkg.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=1)
 lib = _lib.lib()
-lib.cfs_debug_trace_begin(0, cap)
+slv.trace(0, cap)
 sl = slice(b, b + 1)
 r = slv.solve(bt.x_init[sl], bt.xR1[sl], bt.ff[sl], bt.caug[sl], bt.obs[sl], noise=bt.noise[sl] if mode != "CFS" else None)
-buf = np.zeros((cap + 1) * 8)
-lib.cfs_debug_trace_read(buf.ctypes.data_as(C.c_void_p))
-n = int(buf[0]); rec = buf[8:8 + n * 8].reshape(n, 8)
+rec = slv.trace(); n = rec.shape[0]
 print("status", r.status, "iter_O", r.iter_O, "total_iter", r.total_iter, "records", n)
 np.save(f"gpurun_out/trace_{mode}_{b}.npy", rec)
 for k in list(range(min(n, 70))) + list(range(max(70, n - 25), n)):
