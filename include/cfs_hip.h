@@ -193,6 +193,11 @@ int cfs_build_terms_device(cfs_problem *p, int B, const double *x0, const double
  * velocities (its default), waypoint 0 dropped, zero velocities; x0 / xg = the route's ends. */
 int cfs_build_terms_from_routes_device(cfs_problem *p, int B, const double *routes, int nwp,
                                        double *x_init, double *xR1, double *ff, double *caug, void *stream);
+/* The same for routes of DIFFERENT lengths, as cfs_rrt_grow_device leaves them: routes is B x nwp_stride x njoint, route b
+ * has nwp[b] >= 2 rows (nwp: DEVICE int array; a route of a single row -- a start inside the goal region -- is treated as
+ * start = goal).  RRTstar_CFS.m:96-100 resamples size(self.route,2) waypoints to horizon+1 samples whatever the length. */
+int cfs_build_terms_from_ragged_routes_device(cfs_problem *p, int B, const double *routes, int nwp_stride, const int *nwp,
+                                              double *x_init, double *xR1, double *ff, double *caug, void *stream);
 
 /* ---- baseline cost ---------------------------------------------------------------------------
  * replaces: Cost_b = EVAL(sys_info).get_Cost_b() (Lib/EVAL.m:75-78, called at main_FANUC.m:131-132) for B problems of the
@@ -289,6 +294,56 @@ int cfs_problem_set_meshes(cfs_problem *p, int nmesh, const cfs_mesh *const *mes
  * i*njoint,:), dm_f without the M200i joint offset, derivest derivatives): see csrc/cfs_chomp.hip for the list. */
 int cfs_chomp_batch(cfs_problem *p, const cfs_batch_in *in, const double *u0, const double *D, const double *epsilon,
                     const cfs_batch_out *out);
+
+/* ---- RRT / RRT* tree growth ---------------------------------------------------------
+ * replaces: RRT_FANUC(obs, sys_info, goal, region_g, region_s, sample_off, ROBOT, SOLVER).find_route() (Lib/RRT_FANUC.m:48-91)
+ * for S independent trees at once -- the seeds Lib/functions/s_Parallel_rrt.m:14-28 spreads over a parfor pool.  One wavefront
+ * grows one tree entirely on the device (nearest neighbour under the `ratial`-weighted norm, 0.1-rad extension, capsule
+ * feasibility against every obstacle with the same FK + distLinSeg + near-zero surrogate as the CFS path, RRT* re-parenting
+ * within `rewire` of the sample, goal test, failure at node_num > MAX_ITER, route back-tracking); the reference's quirks are
+ * kept (csrc/cfs_rrt.hip lists them).  MATLAB's rand stream cannot be reproduced: pass the uniforms (S x ndraw, consumed as
+ * the reference consumes rand: one per proposal, nstate more when the sample is random) or NULL + a seed for the library's
+ * counter-based generator (u = splitmix64 finaliser of seed + tree*0x9E3779B97F4A7C15 + (counter+1)*0xBF58476D1CE4E5B9,
+ * top 53 bits * 2^-53). */
+typedef enum cfs_rrt_solver { CFS_RRT = 0, CFS_RRT_STAR = 1 } cfs_rrt_solver;   /* SOLVER 'RRT' | 'RRT*' (Lib/RRT_FANUC.m:70-84) */
+typedef struct cfs_rrt_desc {
+    cfs_robot robot;          /* sys_info.robot (+ ROBOT: robot.kind decides the theta(2) - pi/2 offset, :158-160)   */
+    int nstate;               /* sys_info.nstate = joints of the tree (2..6)                                         */
+    int solver;               /* cfs_rrt_solver                                                                      */
+    int max_iter;             /* MAX_ITER (400, :37); <= 1000                                                        */
+    double bi;                /* goal bias threshold (0.5, :38): pp < bi -> random sample, else goal_th              */
+    double rewire;            /* RRT* re-parenting radius around the sample (0.2, :135)                              */
+    int per_tree;             /* 0: x0 / goal / goal_th are nstate vectors shared by all trees; 1: S x nstate         */
+    const double *x0;         /* sys_info.x0                                                                         */
+    const double *goal;       /* goal (centre of the goal region, :195-197)                                          */
+    const double *goal_th;    /* sys_info.goal_th (the biased sample, :113)                                          */
+    const double *region_g, *region_s, *sample_off, *ratial;   /* nstate each (:108-111, :117, :195-197)             */
+    int nobs;
+    const double *obs;        /* nobs x 6: [obs{j}.l(:,1); obs{j}.l(:,2)]                                            */
+    const double *D;          /* nobs: obs{j}.D (:174)                                                               */
+    const double *uniforms;   /* S x ndraw draws of rand, or NULL                                                    */
+    int ndraw;
+    unsigned long long seed;  /* generator mode (uniforms == NULL)                                                   */
+    long long max_draws;      /* generator mode: uniforms a tree may consume before it gives up (fail = 2)           */
+} cfs_rrt_desc;
+typedef struct cfs_rrt_out {
+    int *node_num;            /* S : self.node_num                                                                    */
+    int *fail;                /* S : 0 route found | 1 node_num > MAX_ITER ("Failed to find path.", :201-205) | 2 the uniforms
+                                     ran out while sampling | 3 RRT* re-parenting closed a cycle (the reference would never return) */
+    int *parent;              /* S x (max_iter+1) : self.all_nodes(1,:) (1-based, -1 for the root)                    */
+    double *nodes;            /* S x (max_iter+1) x nstate : self.all_nodes(2:end,:)' (one node per row)              */
+    double *total_dis;        /* S x (max_iter+1) : self.total_dis                                                    */
+    double *all_ee;           /* S x max_iter x 3 : self.all_ee' (may be NULL)                                        */
+    int *route_len;           /* S : size(self.route,2)                                                               */
+    double *route;            /* S x (max_iter+1) x nstate : self.route' (first route_len rows), start to goal       */
+    long long *draws_used;    /* S : uniforms consumed (may be NULL)                                                  */
+    long long *proposals;     /* S : getRandNode calls (may be NULL)                                                  */
+} cfs_rrt_out;
+/* HOST pointers in the descriptor and in `out`; copies in, grows, copies out, synchronises */
+int cfs_rrt_grow(const cfs_rrt_desc *d, int S, const cfs_rrt_out *out);
+/* DEVICE pointers (every array of the descriptor and of `out`; the descriptor struct itself is host memory), enqueued on
+ * `stream`; routes can go straight into cfs_build_terms_from_ragged_routes_device */
+int cfs_rrt_grow_device(const cfs_rrt_desc *d, int S, const cfs_rrt_out *out, void *stream);
 
 /* ---- developer / test entry points -------------------------------------------------------------------
  * No caller of the path needs these; they exist so that every shortcut the solver takes can be switched off and compared

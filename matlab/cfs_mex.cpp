@@ -12,6 +12,10 @@
 //   [d, linkid] = cfs_mex('dist_arm', theta, obs_l, robot, ROBOT)  % dist_arm_3D_200i_2 / dist_arm_3D_Heu_2 / dist_arm_2L(theta, base, obs_l, robot)
 //        theta = njoint x N (one pose per column), obs_l = 3x2 obstacle axis (or 6 x nobs, one [l(:,1); l(:,2)] per column): the
 //        geometry kernel RRT_FANUC.feasible (Lib/RRT_FANUC.m:146-181) and get_con (Lib/CFS_FANUC.m:115) call; d, linkid = nobs x N
+//   [route, all_nodes, total_dis, all_ee, fail, node_num] = cfs_mex('rrt', obs, sys_info, goal, region_g, region_s, sample_off, ROBOT, SOLVER, U)
+//        RRT_FANUC(obs, sys_info, goal, region_g, region_s, sample_off, ROBOT, SOLVER).find_route() (Lib/RRT_FANUC.m:48-91) grown on the GPU;
+//        U = rand(ndraw, S): MATLAB's own rand, consumed per tree exactly as find_route consumes it (one per proposal + nstate for a random
+//        sample); S > 1 grows S seeds at once (s_Parallel_rrt.m:16's parfor) and the outputs become cells
 //   Cost_b = cfs_mex('cost_b', sys_info, ROBOT)                    % EVAL.get_Cost_b (Lib/EVAL.m:75-78, main_FANUC.m:131-132)
 //   h = cfs_mex('mesh_load_stl', path, scale, map_from_stl)        % Lib/functions/MapFromSTL.m
 //   [dis, points] = cfs_mex('mesh_segment_distance', h, seg6)      % point2surface_dis (M200i/dist_arm_surf_200i.m:21)
@@ -191,6 +195,60 @@ static void dist_arm(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     if (nlhs > 1) plhs[1] = ol; else mxDestroyArray(ol);
 }
 
+// RRT_FANUC.find_route for S = size(U,2) seeds (Lib/RRT_FANUC.m:63-91; Lib/functions/s_Parallel_rrt.m:16-25)
+static void rrt(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
+{
+    if (nrhs < 10) mexErrMsgTxt("cfs_mex('rrt', obs, sys_info, goal, region_g, region_s, sample_off, ROBOT, SOLVER, U)");
+    const mxArray *obs = prhs[1], *S_ = prhs[2];
+    const std::string ROBOT = mxArrayToString(prhs[7]), SOLVER = mxArrayToString(prhs[8]);
+    cfs_rrt_desc d;
+    memset(&d, 0, sizeof d);
+    d.nstate = (int)field_scalar(S_, "nstate");
+    fill_robot(mxGetField(S_, 0, "robot"), ROBOT.c_str(), d.nstate, d.robot);
+    d.solver = SOLVER == "RRT*" ? CFS_RRT_STAR : CFS_RRT;
+    d.max_iter = 400; d.bi = 0.5; d.rewire = 0.2;                                   // class property defaults (Lib/RRT_FANUC.m:37-38, :135)
+    d.x0 = field_ptr(S_, "x0"); d.goal_th = field_ptr(S_, "goal_th"); d.ratial = field_ptr(S_, "ratial");
+    d.goal = mxGetPr(prhs[3]); d.region_g = mxGetPr(prhs[4]); d.region_s = mxGetPr(prhs[5]); d.sample_off = mxGetPr(prhs[6]);
+    const int nobs = (int)mxGetNumberOfElements(obs);
+    std::vector<double> obs6(6 * (size_t)nobs), D(nobs);
+    for (int j = 0; j < nobs; ++j) {
+        const mxArray *o = mxGetCell(obs, j), *fl = o ? mxGetField(o, 0, "l") : nullptr, *fD = o ? mxGetField(o, 0, "D") : nullptr;
+        if (!fl || !fD || mxGetNumberOfElements(fl) != 6) mexErrMsgIdAndTxt("cfs:obs", "obs{%d} needs .l (3x2) and .D", j + 1);
+        memcpy(&obs6[6 * (size_t)j], mxGetPr(fl), sizeof(double) * 6);
+        D[j] = mxGetScalar(fD);
+    }
+    d.nobs = nobs; d.obs = obs6.data(); d.D = D.data();
+    const int ndraw = (int)mxGetM(prhs[9]), S = (int)mxGetN(prhs[9]);
+    d.uniforms = mxGetPr(prhs[9]); d.ndraw = ndraw;                                 // ndraw x S column-major = S x ndraw row-major
+    const size_t N = (size_t)d.max_iter + 1, nj = d.nstate;
+    std::vector<int> node_num(S), fail(S), route_len(S), parent(S * N);
+    std::vector<double> nodes(S * N * nj), total_dis(S * N), all_ee((size_t)S * d.max_iter * 3), route(S * N * nj);
+    cfs_rrt_out o;
+    memset(&o, 0, sizeof o);
+    o.node_num = node_num.data(); o.fail = fail.data(); o.route_len = route_len.data(); o.parent = parent.data();
+    o.nodes = nodes.data(); o.total_dis = total_dis.data(); o.all_ee = all_ee.data(); o.route = route.data();
+    check(cfs_rrt_grow(&d, S, &o));
+    mxArray *outs[6];
+    for (int k = 0; k < 4; ++k) outs[k] = S > 1 ? mxCreateCellMatrix(1, S) : nullptr;
+    outs[4] = mxCreateDoubleMatrix(1, S, mxREAL); outs[5] = mxCreateDoubleMatrix(1, S, mxREAL);
+    for (int t = 0; t < S; ++t) {
+        const int n = node_num[t], L = route_len[t];
+        mxArray *r = mxCreateDoubleMatrix(nj, L, mxREAL), *an = mxCreateDoubleMatrix(nj + 1, n, mxREAL);
+        mxArray *td = mxCreateDoubleMatrix(1, n, mxREAL), *ee = mxCreateDoubleMatrix(3, n > 0 ? n - 1 : 0, mxREAL);
+        memcpy(mxGetPr(r), &route[(size_t)t * N * nj], sizeof(double) * nj * L);      // rows of `route` are MATLAB's columns
+        for (int i = 0; i < n; ++i) {
+            mxGetPr(an)[(size_t)i * (nj + 1)] = parent[(size_t)t * N + i];            // all_nodes = [parent; node] (Lib/RRT_FANUC.m:66, :185)
+            memcpy(mxGetPr(an) + (size_t)i * (nj + 1) + 1, &nodes[((size_t)t * N + i) * nj], sizeof(double) * nj);
+            mxGetPr(td)[i] = total_dis[(size_t)t * N + i];
+        }
+        if (n > 1) memcpy(mxGetPr(ee), &all_ee[(size_t)t * d.max_iter * 3], sizeof(double) * 3 * (n - 1));
+        mxArray *one[4] = {r, an, td, ee};
+        for (int k = 0; k < 4; ++k) { if (S > 1) mxSetCell(outs[k], t, one[k]); else outs[k] = one[k]; }
+        mxGetPr(outs[4])[t] = fail[t]; mxGetPr(outs[5])[t] = n;
+    }
+    for (int k = 0; k < 6; ++k) { if (k < nlhs || k == 0) plhs[k] = outs[k]; else mxDestroyArray(outs[k]); }
+}
+
 // Cost_b = EVAL(sys_info).get_Cost_b()  (Lib/EVAL.m:75-78)
 static void cost_b(mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
@@ -225,6 +283,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         chomp(nlhs, plhs, nrhs, prhs);
     } else if (cmd == "dist_arm") {
         dist_arm(nlhs, plhs, nrhs, prhs);
+    } else if (cmd == "rrt") {
+        rrt(nlhs, plhs, nrhs, prhs);
     } else if (cmd == "cost_b") {
         cost_b(plhs, nrhs, prhs);
     } else if (cmd == "mesh_load_stl") {

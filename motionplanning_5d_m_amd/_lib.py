@@ -108,6 +108,47 @@ class cfs_batch_out(C.Structure):
     ]
 
 
+class cfs_rrt_desc(C.Structure):
+    _fields_ = [
+        ("robot", cfs_robot),
+        ("nstate", C.c_int),
+        ("solver", C.c_int),
+        ("max_iter", C.c_int),
+        ("bi", C.c_double),
+        ("rewire", C.c_double),
+        ("per_tree", C.c_int),
+        ("x0", C.c_void_p),
+        ("goal", C.c_void_p),
+        ("goal_th", C.c_void_p),
+        ("region_g", C.c_void_p),
+        ("region_s", C.c_void_p),
+        ("sample_off", C.c_void_p),
+        ("ratial", C.c_void_p),
+        ("nobs", C.c_int),
+        ("obs", C.c_void_p),
+        ("D", C.c_void_p),
+        ("uniforms", C.c_void_p),
+        ("ndraw", C.c_int),
+        ("seed", C.c_ulonglong),
+        ("max_draws", C.c_longlong),
+    ]
+
+
+class cfs_rrt_out(C.Structure):
+    _fields_ = [
+        ("node_num", C.c_void_p),
+        ("fail", C.c_void_p),
+        ("parent", C.c_void_p),
+        ("nodes", C.c_void_p),
+        ("total_dis", C.c_void_p),
+        ("all_ee", C.c_void_p),
+        ("route_len", C.c_void_p),
+        ("route", C.c_void_p),
+        ("draws_used", C.c_void_p),
+        ("proposals", C.c_void_p),
+    ]
+
+
 # every symbol include/cfs_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
@@ -139,6 +180,9 @@ SYMBOLS = [
     ("cfs_dist_arm_mesh", C.c_int, [C.POINTER(cfs_robot), C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     ("cfs_problem_set_meshes", C.c_int, [_P, C.c_int, _P]),
     ("cfs_chomp_batch", C.c_int, [_P, C.POINTER(cfs_batch_in), _P, _P, _P, C.POINTER(cfs_batch_out)]),
+    ("cfs_build_terms_from_ragged_routes_device", C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    ("cfs_rrt_grow", C.c_int, [C.POINTER(cfs_rrt_desc), C.c_int, C.POINTER(cfs_rrt_out)]),
+    ("cfs_rrt_grow_device", C.c_int, [C.POINTER(cfs_rrt_desc), C.c_int, C.POINTER(cfs_rrt_out), _P]),
     ("cfs_cost_b", C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     ("cfs_get_cost", C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     ("cfs_debug_set_options", C.c_int, [_P, C.c_int, C.c_int, C.c_double]),

@@ -930,7 +930,7 @@ int cfs_build_terms_device(cfs_problem *p, int B, const double *x0, const double
     HIPCHK(hipSetDevice(p->device));
     TermsParams t;
     t.B = B; t.H = p->d.H; t.nj = p->d.njoint; t.F1 = p->F1.p; t.F2 = p->F2.p; t.Cq = p->Cq.p;
-    t.x0 = x0; t.xg = xg; t.route = nullptr; t.nwp = 0; t.dt = p->d.robot.delta_t;
+    t.x0 = x0; t.xg = xg; t.route = nullptr; t.nwp = 0; t.nwp_b = nullptr; t.nwp_stride = 0; t.dt = p->d.robot.delta_t;
     t.x_init = x_init; t.xR1 = xR1; t.ff = ff; t.caug = caug;
     launch_build_terms(t, reinterpret_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
@@ -946,7 +946,23 @@ int cfs_build_terms_from_routes_device(cfs_problem *p, int B, const double *rout
     HIPCHK(hipSetDevice(p->device));
     TermsParams t;
     t.B = B; t.H = p->d.H; t.nj = p->d.njoint; t.F1 = p->F1.p; t.F2 = p->F2.p; t.Cq = p->Cq.p;
-    t.x0 = nullptr; t.xg = nullptr; t.route = routes; t.nwp = nwp; t.dt = p->d.robot.delta_t;
+    t.x0 = nullptr; t.xg = nullptr; t.route = routes; t.nwp = nwp; t.nwp_b = nullptr; t.nwp_stride = 0; t.dt = p->d.robot.delta_t;
+    t.x_init = x_init; t.xR1 = xR1; t.ff = ff; t.caug = caug;
+    launch_build_terms(t, reinterpret_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return CFS_SUCCESS;
+}
+
+int cfs_build_terms_from_ragged_routes_device(cfs_problem *p, int B, const double *routes, int nwp_stride, const int *nwp,
+                                              double *x_init, double *xR1, double *ff, double *caug, void *stream)
+{
+    if (!p || !routes || !nwp || !x_init || !xR1 || !ff || !caug) return fail(CFS_ERR_INVALID_ARG, "NULL argument");
+    if (B < 1 || nwp_stride < 1) return fail(CFS_ERR_INVALID_ARG, "B >= 1 and nwp_stride >= 1 are needed");
+    if (!p->F1.p) return fail(CFS_ERR_INVALID_ARG, "call cfs_set_state_cost first");
+    HIPCHK(hipSetDevice(p->device));
+    TermsParams t;
+    t.B = B; t.H = p->d.H; t.nj = p->d.njoint; t.F1 = p->F1.p; t.F2 = p->F2.p; t.Cq = p->Cq.p;
+    t.x0 = nullptr; t.xg = nullptr; t.route = routes; t.nwp = nwp_stride; t.nwp_b = nwp; t.nwp_stride = nwp_stride; t.dt = p->d.robot.delta_t;
     t.x_init = x_init; t.xR1 = xR1; t.ff = ff; t.caug = caug;
     launch_build_terms(t, reinterpret_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());

@@ -162,6 +162,8 @@ struct TermsParams {             // per-problem line reference and cost terms fr
     const double *x0, *xg;       // B x nj
     const double *route;         // optional, B x nwp x nj (waypoint-major): x0 / xg are its ends, x_init its cubic resampling
     int nwp;
+    const int *nwp_b;            // optional, B: rows of route b actually used (ragged routes, stride nwp_stride rows per problem)
+    int nwp_stride;
     double dt;
     double *x_init, *xR1, *ff, *caug;
 };

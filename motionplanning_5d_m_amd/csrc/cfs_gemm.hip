@@ -81,9 +81,10 @@ __global__ __launch_bounds__(CFS_WAVE) void cfs_cost_history_kernel(CostHistPara
 __global__ __launch_bounds__(CFS_WAVE) void cfs_build_terms_kernel(TermsParams P)
 {
     const int b = blockIdx.x, lane = threadIdx.x, nj = P.nj, H = P.H, nn = H * nj, ns = 2 * nj;
-    const double *rt = P.route ? P.route + (size_t)b * P.nwp * nj : nullptr;
+    const int nwp = P.nwp_b ? max(P.nwp_b[b], 1) : P.nwp;        // routes of different lengths: B x nwp_stride x nj, nwp_b[b] rows used
+    const double *rt = P.route ? P.route + (size_t)b * (P.nwp_b ? P.nwp_stride : P.nwp) * nj : nullptr;
     const double *x0 = rt ? rt : P.x0 + (size_t)b * nj;
-    const double *xg = rt ? rt + (size_t)(P.nwp - 1) * nj : P.xg + (size_t)b * nj;
+    const double *xg = rt ? rt + (size_t)(nwp - 1) * nj : P.xg + (size_t)b * nj;
     for (int k = lane; k < nn; k += CFS_WAVE) {
         double s = 0.0;
         for (int c = 0; c < nj; ++c) s += P.F1[k + (size_t)c * nn] * x0[c] - P.F2[k + (size_t)c * nn] * xg[c];
@@ -93,15 +94,16 @@ __global__ __launch_bounds__(CFS_WAVE) void cfs_build_terms_kernel(TermsParams P
         const int i = e / ns, c = e - i * ns;
         double v = 0.0;
         if (c < nj && !rt) v = (i == H - 1) ? xg[c] : x0[c] + (double)(i + 1) * ((xg[c] - x0[c]) / (double)H);
-        if (c < nj && rt) {
+        if (c < nj && rt && nwp < 2) v = rt[c];                  // a one-node route (start inside the goal region): stay there
+        if (c < nj && rt && nwp >= 2) {
             // cubicpolytraj(route, (0:nwp-1)*dt, linspace(0, (nwp-1)*dt, H+1)) with zero waypoint velocities
             // (RRTstar_CFS.m:94-100): sample n = i+1 lies in segment k, tau in [0,1], value r_k + (3 tau^2 - 2 tau^3)(r_k+1 - r_k)
-            const double T = (double)(P.nwp - 1) * P.dt;
+            const double T = (double)(nwp - 1) * P.dt;
             const double t = (i == H - 1) ? T : (double)(i + 1) * (T / (double)H);
             int k = (int)floor(t / P.dt);
             while ((double)(k + 1) * P.dt <= t) ++k;
             while (k > 0 && (double)k * P.dt > t) --k;
-            k = min(max(k, 0), P.nwp - 2);
+            k = min(max(k, 0), nwp - 2);
             const double t0 = (double)k * P.dt, t1 = (double)(k + 1) * P.dt;
             const double tau = (t - t0) / (t1 - t0);
             const double r0 = rt[(size_t)k * nj + c], r1 = rt[(size_t)(k + 1) * nj + c];

@@ -80,3 +80,22 @@ struct ChompParams {
 hipError_t launch_chomp(int nj, const ChompParams &p, hipStream_t s);
 void chomp_derivest_tables(ChompParams &p);
 bool chomp_fits(int nj, int H, int nobs);
+
+// ---- RRT / RRT* tree growth (cfs_rrt.hip) ---------------------------------------------------------------------
+struct RrtParams {
+    DevRobot rb;                                         // by value: no device allocation, no synchronisation in the _device entry
+    int S, nobs, solver, max_iter, per_tree;             // trees; obstacles; 0 RRT | 1 RRT*; MAX_ITER; 1: x0 / goal / goal_th are S x nstate
+    double bi, rewire;                                   // goal bias threshold (0.5, RRT_FANUC.m:38), re-parenting radius (0.2, :135)
+    const double *x0, *goal, *goal_th;                   // nstate (or S x nstate)
+    const double *region_g, *region_s, *sample_off, *ratial;   // nstate
+    const double *obs, *D;                               // nobs x 6, nobs
+    const double *uniforms;                              // S x ndraw or null (then the counter-based generator with `seed`)
+    int ndraw;
+    unsigned long long seed;
+    long long max_draws;                                 // generator mode: uniforms a tree may consume before it gives up (fail = 2)
+    int *node_num, *fail, *parent, *route_len;           // S, S, S x (max_iter+1), S
+    double *nodes, *total_dis, *all_ee, *route;          // S x (max_iter+1) x nstate, S x (max_iter+1), S x max_iter x 3 (may be null), S x (max_iter+1) x nstate
+    long long *draws_used, *proposals;                   // S (may be null)
+};
+hipError_t launch_rrt(int nj, const RrtParams &p, hipStream_t s);
+size_t rrt_lds_bytes(int nj, int max_iter);

@@ -281,6 +281,20 @@ class CFSBatch:
                                                                 _ptr(caug), C.c_void_p(stream)))
         return x_init, xR1, ff, caug
 
+    def build_terms_from_ragged_routes_device(self, routes, nwp, stream=None):
+        """The same for routes of different lengths as cfs_rrt_grow_device leaves them: routes (B, nwp_stride, njoint) CUDA
+        float64, nwp (B,) CUDA int32 rows used per route (cfs_build_terms_from_ragged_routes_device)."""
+        B, stride = routes.shape[0], routes.shape[1]
+        assert routes.is_cuda and routes.dtype == torch.float64 and routes.is_contiguous() and routes.shape[2] == self.nj
+        assert nwp.is_cuda and nwp.dtype == torch.int32 and nwp.is_contiguous() and nwp.shape == (B,)
+        z = lambda *sh: torch.empty(*sh, dtype=torch.float64, device=routes.device)  # noqa: E731
+        x_init, xR1, ff, caug = z(B, self.nx), z(B, self.ns), z(B, self.nn), z(B)
+        if stream is None:
+            stream = torch.cuda.current_stream(routes.device).cuda_stream
+        _lib.check(self._lib.cfs_build_terms_from_ragged_routes_device(self._h, B, _ptr(routes), stride, _ptr(nwp), _ptr(x_init), _ptr(xR1),
+                                                                       _ptr(ff), _ptr(caug), C.c_void_p(stream)))
+        return x_init, xR1, ff, caug
+
     # ---- measurement ------------------------------------------------------------------------------
     def profile(self, on=True):
         _lib.check(self._lib.cfs_profile_enable(self._h, 1 if on else 0))

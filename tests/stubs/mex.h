@@ -28,6 +28,8 @@ bool mxIsChar(const mxArray *pm);
 bool mxIsEmpty(const mxArray *pm);
 mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity ComplexFlag);
 mxArray *mxCreateDoubleScalar(double value);
+mxArray *mxCreateCellMatrix(mwSize m, mwSize n);
+void mxSetCell(mxArray *pm, mwIndex index, mxArray *value);
 mxArray *mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID classid, mxComplexity ComplexFlag);
 void mxDestroyArray(mxArray *pm);
 void mexErrMsgTxt(const char *errormsg);

@@ -21,7 +21,7 @@ def test_mex_gateway_calls_only_declared_entry_points():
     used = set(re.findall(r"\b(cfs_[a-z_]+)\s*\(", src)) - {"cfs_mex"}          # cfs_mex(...) appears in the usage comments
     declared = set(re.findall(r"\b(cfs_[a-z_]+)\s*\(", hdr))
     assert used and used <= declared, used - declared
-    for cmd in ("solve", "get_con", "chomp", "dist_arm", "cost_b", "mesh_load_stl", "mesh_segment_distance", "mesh_destroy"):
+    for cmd in ("solve", "get_con", "chomp", "dist_arm", "rrt", "cost_b", "mesh_load_stl", "mesh_segment_distance", "mesh_destroy"):
         assert f'"{cmd}"' in src
 
 
@@ -40,6 +40,12 @@ def test_classdefs_keep_the_reference_interface():
     for name in ("CFS_FANUC", "PSGCFS_FANUC"):
         txt = open(os.path.join(ROOT, "matlab", name + ".m")).read()
         assert "Ainq" in txt and "binq" in txt
+    # RRT_FANUC: constructor and find_route with the reference's signature and outputs (Lib/RRT_FANUC.m:48,63)
+    txt = open(os.path.join(ROOT, "matlab", "RRT_FANUC.m")).read()
+    assert re.search(r"function\s+self\s*=\s*RRT_FANUC\(val,\s*val2,\s*val3,\s*val4,\s*val5,\s*val6,\s*varargin\)", txt)
+    assert re.search(r"function\s+self\s*=\s*find_route\(self\)", txt) and "cfs_mex('rrt'" in txt
+    for prop in ("route", "all_nodes", "total_dis", "all_ee", "fail", "node_num", "MAX_ITER", "bi"):
+        assert re.search(r"\b" + prop + r"\b", txt), prop
     # the geometry primitive under its reference name and signature (Lib/200i/dist_arm_3D_200i_2.m:1)
     txt = open(os.path.join(ROOT, "matlab", "dist_arm_3D_200i_2.m")).read()
     assert re.search(r"function\s+\[d,\s*linkid\]\s*=\s*dist_arm_3D_200i_2\(theta,\s*base,\s*obs,\s*robot\)", txt) and "cfs_mex('dist_arm'" in txt

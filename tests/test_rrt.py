@@ -1,5 +1,7 @@
-"""Row f1: RRT / RRT* (Lib/RRT_FANUC.m, Lib/functions/s_Parallel_rrt.m).  CPU: the oracle restatement is
-self-consistent; GPU: the host mirror with batched GPU feasibility grows the same trees node for node."""
+"""Row f1: RRT / RRT* (Lib/RRT_FANUC.m, Lib/functions/s_Parallel_rrt.m).  CPU: the oracle restatement is self-consistent;
+GPU: cfs_rrt_grow -- whole trees grown on the device, one wavefront per tree -- gives the same trees node for node:
+parents, node coordinates, costs and routes are BIT-identical to the oracle (the kernel's tree arithmetic is compiled without
+FMA contraction; oracle/rrt_oracle.py sums left to right in IEEE double), all_ee to 1e-13 (device sin / cos vs libm)."""
 import numpy as np
 import pytest
 
@@ -36,23 +38,135 @@ def test_oracle_rrt_routes_are_valid(O):
     assert found >= 1
 
 
+def _oracle_tree(args):
+    """one tree by the CPU restatement (runs in a spawned worker: the oracle's tree loop is Python)"""
+    import sys
+    sys.path.insert(0, args[0])
+    from oracle import oracle as O2, rrt_oracle as R
+    _, solver, u, x0, goal = args
+    robot, obs, x0d, goald, rg, rs, ratial = _setup(O2)
+    x0 = x0d if x0 is None else x0
+    goal = goald if goal is None else goal
+    return R.find_route(robot, obs, x0, goal, goal, rg, rs, np.zeros(5), ratial, R.ArrayRng(u), solver)
+
+
+def _oracle_trees(solver, U, x0=None, goal=None):
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jobs = [(root, solver, U[t], None if x0 is None else x0[t], None if goal is None else goal[t]) for t in range(U.shape[0])]
+    with cf.ProcessPoolExecutor(min(16, os.cpu_count() or 1), mp_context=mp.get_context("spawn")) as ex:   # never fork a process that holds the GPU
+        return list(ex.map(_oracle_tree, jobs, chunksize=2))
+
+
+def _same_tree(r, w, tag):
+    assert r.node_num == w["node_num"] and r.fail_code == w["fail_code"], (tag, r.node_num, w["node_num"], r.fail_code, w["fail_code"])
+    np.testing.assert_array_equal(r.all_nodes, w["all_nodes"], err_msg=f"{tag}: parents / nodes")     # bit for bit
+    np.testing.assert_array_equal(r.total_dis, w["total_dis"], err_msg=f"{tag}: total_dis")
+    np.testing.assert_array_equal(r.route, w["route"], err_msg=f"{tag}: route")
+    np.testing.assert_allclose(r.all_ee, w["all_ee"], rtol=0, atol=1e-13, err_msg=f"{tag}: all_ee")
+    assert r.proposals == w["proposals"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver", ["RRT", "RRT*"])
-def test_rrt_trees_match_oracle_node_for_node(gpu, O, solver):
-    from oracle import rrt_oracle as R
-    robot, obs, x0, goal, rg, rs, ratial = _setup(O)
+def test_device_rrt_trees_match_oracle_node_for_node(gpu, solver):
+    """64 seeds of RRTstar_CFS.m's own planning problem (start, goal, two obstacles, regions: RRTstar_CFS.m:16-64), pre-drawn
+    uniforms consumed as the reference consumes rand.  About half of the seeds fail at MAX_ITER = 400 -- as in the reference,
+    which is why s_Parallel_rrt.m:14 retries -- and failures must agree too."""
     pobs, s, g, region_g, region_s, off = gpu.RRTstar_problem()
     planner = gpu.RRT_FANUC(pobs, s, g, region_g, region_s, off, "M200i", solver)
-    seeds = [1, 2, 3, 5]
-    got = planner.grow([np.random.default_rng(sd) for sd in seeds])                  # 4 trees in lock-step, batched feasibility
-    for sd, r in zip(seeds, got):
-        w = R.find_route(robot, obs, x0, goal, goal, rg, rs, np.zeros(5), ratial, np.random.default_rng(sd), solver)
-        assert r.node_num == w["node_num"] and r.fail == w["fail"]
-        np.testing.assert_array_equal(r.all_nodes[0], w["all_nodes"][0])              # parent indices
-        np.testing.assert_allclose(r.all_nodes[1:], w["all_nodes"][1:], rtol=0, atol=1e-12)
-        np.testing.assert_allclose(r.total_dis, w["total_dis"], rtol=0, atol=1e-10)
-        np.testing.assert_allclose(r.route, w["route"], rtol=0, atol=1e-12)
-        np.testing.assert_allclose(r.all_ee, w["all_ee"], rtol=0, atol=1e-12)
+    S = 64
+    U = np.stack([np.random.default_rng(1000 + sd).random(6 * 8 * 401) for sd in range(S)])
+    got = planner.grow(uniforms=U)
+    want = _oracle_trees(solver, U)
+    for t in range(S):
+        _same_tree(got[t], want[t], f"{solver} seed {t}")
+    ok = [r for r in got if not r.fail]
+    print(f"[device {solver}] {len(ok)} of {S} seeds reach the goal; nodes per tree {np.mean([r.node_num for r in got]):.0f}, "
+          f"proposals per tree {np.mean([r.proposals for r in got]):.0f}, route lengths {sorted(r.route.shape[1] for r in ok)[:5]}...")
+    assert 8 <= len(ok) < S
+    for r in ok[:8]:                                                                       # properties of a found route
+        np.testing.assert_array_equal(r.route[:, 0], s.x0)
+        assert np.all(np.abs(r.route[:, -1] - g) < region_g)
+        np.testing.assert_allclose(np.linalg.norm(np.diff(r.route, axis=1), axis=0), 0.1, atol=1e-12)
+    # numpy Generators give the same trees as their pre-drawn streams (Generator.random(n) is the concatenation of n draws)
+    again = planner.grow([np.random.default_rng(1000 + sd) for sd in range(4)])
+    for t in range(4):
+        np.testing.assert_array_equal(again[t].all_nodes, got[t].all_nodes)
+
+
+@pytest.mark.gpu
+def test_device_rrt_generator_per_tree_goals_and_exhaustion(gpu, O):
+    """(i) the library's counter-based generator (include/cfs_hip.h) restated in integer arithmetic feeds the oracle the same
+    uniforms: same trees; (ii) per-tree start / goal; (iii) a stream that runs out ends the tree with fail = 2, on both sides;
+    (iv) a start inside the goal region is a one-node route; (v) the device-resident entry returns the same routes."""
+    import torch
+    from oracle import rrt_oracle as R
+    pobs, s, g, region_g, region_s, off = gpu.RRTstar_problem()
+    planner = gpu.RRT_FANUC(pobs, s, g, region_g, region_s, off, "M200i", "RRT*")
+    S, seed, nd = 12, 20260103, 6 * 8 * 401
+    rng = np.random.default_rng(5)
+    x0 = np.tile(s.x0, (S, 1)) + rng.uniform(-0.05, 0.05, (S, 5))
+    goal = np.tile(g, (S, 1)) + rng.uniform(-0.05, 0.05, (S, 5))
+    goal[3] = x0[3]                                                                       # (iv)
+    got = planner.grow(seed=seed, S=S, x0=x0, goal=goal)
+    U = np.stack([R.splitmix_uniforms(seed, t, nd) for t in range(S)])
+    want = _oracle_trees("RRT*", U, x0=x0, goal=goal)
+    for t in range(S):
+        _same_tree(got[t], want[t], f"generator tree {t}")
+    assert got[3].node_num == 1 and got[3].route.shape == (5, 1) and not got[3].fail
+    short = planner.grow(uniforms=U[:, :300], x0=x0, goal=goal)                          # (iii)
+    want_s = _oracle_trees("RRT*", U[:, :300], x0=x0, goal=goal)
+    assert sum(r.fail_code == 2 for r in short) >= 6
+    for t in range(S):
+        _same_tree(short[t], want_s[t], f"short stream tree {t}")
+    dev = torch.device("cuda", 0)
+    td = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()  # noqa: E731
+    r = planner.grow_device(S, seed, dev, x0=td(x0), goal=td(goal), want_tree=True)       # (v)
+    torch.cuda.synchronize()
+    for t in range(S):
+        L = int(r.route_len[t])
+        np.testing.assert_array_equal(r.route[t, :L].cpu().numpy().T, got[t].route)
+        assert int(r.fail[t]) == got[t].fail_code and int(r.node_num[t]) == got[t].node_num
+
+
+@pytest.mark.gpu
+def test_ragged_routes_to_cfs_terms(gpu, O):
+    """cfs_build_terms_from_ragged_routes_device: routes of different lengths, as the device RRT leaves them, resampled to
+    H + 1 = 41 points (RRTstar_CFS.m:94-100) and turned into (x_init, xR1, ff, caug) on the device, against the oracle's
+    cubicpolytraj restatement and the host cost terms."""
+    import torch
+    from motionplanning_5d_m_amd import workloads
+    from motionplanning_5d_m_amd.sysinfo import cost_terms
+    pobs, s_r, g, region_g, region_s, off = gpu.RRTstar_problem()
+    planner = gpu.RRT_FANUC(pobs, s_r, g, region_g, region_s, off, "M200i", "RRT")
+    dev = torch.device("cuda", 0)
+    S = 48
+    r = planner.grow_device(S, 7, dev)
+    torch.cuda.synchronize()
+    okm = (r.fail == 0).cpu().numpy()
+    assert okm.sum() >= 6
+    route_wp = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "route_wp_200i_xori.npy"))
+    s, bt = workloads.config4(route_wp, B=2)
+    slv = gpu.CFSBatch(s, 2, bt.margin_cfs, mode="CFS", max_batch=S)
+    x_init, xR1, ff, caug = [v.cpu().numpy() for v in slv.build_terms_from_ragged_routes_device(r.route, r.route_len)]
+    H, dt = s.H, s.robot.delta_t
+    routes, lens = r.route.cpu().numpy(), r.route_len.cpu().numpy()
+    assert len(set(lens[okm].tolist())) > 1                                              # really ragged
+    for b in np.nonzero(okm)[0][:12]:
+        nwp = int(lens[b])
+        rt = routes[b, :nwp]                                                              # (nwp, 5)
+        want = O.cubicpolytraj_zero_vel(rt.T, np.arange(nwp) * dt, np.linspace(0, (nwp - 1) * dt, H + 1))
+        th = x_init[b].reshape(H, 10)
+        np.testing.assert_allclose(th[:, :5], want[:, 1:].T, rtol=0, atol=1e-13)
+        assert np.all(th[:, 5:] == 0)
+        np.testing.assert_array_equal(xR1[b], np.concatenate([rt[0], np.zeros(5)]))
+        f, c = cost_terms(s.Aaug, s.Baug, s.Qaug_state, xR1[b], rt[-1], H, 5)
+        np.testing.assert_allclose(ff[b], f, rtol=1e-11, atol=1e-9)
+        assert abs(caug[b] - c) <= 1e-11 * abs(c)
+    slv.close()
 
 
 @pytest.mark.gpu

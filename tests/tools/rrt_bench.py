@@ -1,0 +1,111 @@
+"""Row f1 + BASELINE config 4 end to end on one GPU: RRT trees grown on the device -> ragged routes -> cubic resampling + cost
+terms on the device -> CFS_FANUC smoothing.  One JSON line.
+
+RRTstar_CFS.m's own planning problem (start, goal, two obstacles, sampling regions: :16-64; plain 'RRT' as s_Parallel_rrt.m:17
+instantiates it), B trees per round from the library's counter-based generator; trees that fail at MAX_ITER = 400 (about half,
+as in the reference, whose s_Parallel_rrt.m:14 loops until a seed succeeds) are regrown with the next seed, up to --rounds
+rounds, and the routes found feed the config-4 CFS stage (H = 40, cost matrices RRTstar_CFS.m:124-187) exactly as the script
+does for its one route.  Reported: trees/s, nodes/s, proposals/s of one B-tree launch (median of 5), and CFS iterations/s of
+the smoothing stage on the grown routes (the oracle checks --check of them).
+usage: python tests/tools/rrt_bench.py [--batch B] [--rounds R] [--steps K] [--check N] [--solver RRT|RRT*]"""
+import argparse, json, os, statistics, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import motionplanning_5d_m_amd as pkg
+from motionplanning_5d_m_amd import workloads
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--check", type=int, default=0); ap.add_argument("--solver", default="RRT"); ap.add_argument("--seed", type=int, default=20260104)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+B = a.batch
+pobs, s_r, g, region_g, region_s, off = pkg.RRTstar_problem()
+planner = pkg.RRT_FANUC(pobs, s_r, g, region_g, region_s, off, "M200i", a.solver)
+
+# ---- tree growth: one launch of B trees, timed alone -----------------------------------------------------------------------------
+r = planner.grow_device(B, a.seed, dev)
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    r = planner.grow_device(B, a.seed, dev)
+    torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+t_grow = statistics.median(ts)
+nodes, props, ok0 = int(r.node_num.sum().item()), int(r.proposals.sum().item()), int((r.fail == 0).sum().item())
+# ---- rounds until every slot has a route (s_Parallel_rrt.m:14: "while all(path_fail)") ---------------------------------------------
+route, route_len, fail = r.route.clone(), r.route_len.clone(), r.fail.clone()
+rounds = 1
+while int((fail != 0).sum().item()) > 0 and rounds < a.rounds:
+    rn = planner.grow_device(B, a.seed + rounds, dev)
+    take = (fail != 0) & (rn.fail == 0)
+    route = torch.where(take[:, None, None], rn.route, route)
+    route_len = torch.where(take, rn.route_len, route_len)
+    fail = torch.where(take, rn.fail, fail)
+    rounds += 1
+torch.cuda.synchronize()
+found = (fail == 0)
+n_found = int(found.sum().item())
+idx = torch.nonzero(found).flatten()
+routes_ok, len_ok = route[idx].contiguous(), route_len[idx].contiguous()
+lens = len_ok.cpu().numpy()
+
+# ---- CFS smoothing of the grown routes (config 4's cost matrices and obstacles) -----------------------------------------------------
+route_wp = np.load(os.path.join(ROOT, "tests", "golden", "route_wp_200i_xori.npy"))
+s, bt = workloads.config4(route_wp, B=2)                   # the family (H = 40, weights, obstacles); its two routes are not used
+S = 2
+slvs = [pkg.CFSBatch(s, 2, bt.margin_cfs, mode="CFS", max_batch=n_found) for _ in range(S)]
+obs = torch.tensor(np.broadcast_to(bt.obs[0], (n_found, 2, 6)).copy(), dtype=torch.float64, device=dev)
+streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+outs = [sl.alloc_outputs(n_found, dev) for sl in slvs]
+
+def step(i):
+    k = i % S
+    with torch.cuda.stream(streams[k]):
+        st_ = streams[k].cuda_stream
+        terms = slvs[k].build_terms_from_ragged_routes_device(routes_ok, len_ok, stream=st_)
+        slvs[k].solve_device(*terms, obs, out=outs[k], stream=st_)
+    return terms
+
+for i in range(3):
+    step(i)
+torch.cuda.synchronize()
+terms = step(0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(a.steps):
+    step(i)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+out = outs[0]
+units = int((out.iter_O - 1).sum().item())
+st = np.bincount(out.status.cpu().numpy(), minlength=4)
+res = {"metric": "RRT trees/s and CFS iterations/s, RRTstar_CFS.m's planning problem, %d trees per launch" % B,
+       "rrt": {"solver": a.solver, "trees_per_launch": B, "ms_per_launch": t_grow * 1e3, "trees_per_s": B / t_grow, "nodes_per_s": nodes / t_grow,
+               "proposals_per_s": props / t_grow, "nodes_per_tree": nodes / B, "proposals_per_tree": props / B,
+               "routes_found_first_round": ok0, "rounds": rounds, "routes_found": n_found,
+               "route_length_min_median_max": [int(lens.min()), float(np.median(lens)), int(lens.max())]},
+       "value": units / dt, "unit": "CFS iterations/s", "n_gpus": 1, "steps": a.steps, "ms_per_step": dt * 1e3, "dtype": "f64", "data": "synthetic",
+       "config": {"workload": "config4 from GROWN routes: %d RRT routes (device), ragged cubic resampling to H=40 + cost terms on the device, CFS_FANUC, "
+                              "2 obstacles, cost matrices RRTstar_CFS.m:124-187" % n_found,
+                  "iterations_per_step": units, "solves_per_s": n_found / dt, "concurrent_solves": S,
+                  "status_counts": {"converged": int(st[0]), "max_iter": int(st[1]), "qp_infeasible": int(st[2]), "numeric": int(st[3])}}}
+if a.check:
+    from oracle import oracle as O
+    n = min(a.check, n_found)
+    x_init, xR1, ff, caug = [v.cpu().numpy() for v in terms]
+    w = O.optimizer_batch(O.robotproperty2("M200i"), "CFS", s.H, 5, x_init[:n], xR1[:n], s.QQ, ff[:n], caug[:n], s.Aaug, s.Baug, s.lim, s.MAX_input,
+                          np.broadcast_to(bt.obs[0], (n, 2, 6)).copy(), bt.margin_cfs, s.epsilon_O, s.MAX_O_ITER, s.alpha)
+    gs, gi, gx = out.status.cpu().numpy()[:n], out.iter_O.cpu().numpy()[:n], out.x_.cpu().numpy()[:n]
+    same = (gs == w.status) & (gi == w.iter_O)
+    ok = same & (gs < 2)
+    err = np.abs(gx - w.x_).max(axis=1)[ok]
+    cost = out.cost_all.cpu().numpy()[:n][np.arange(n), np.maximum(gi - 2, 0)]
+    res["accuracy"] = {"vs": "CPU oracle (parity unpinned; unclassified sample)", "problems": n, "status_and_iteration_agreement": float(same.mean()),
+                       "linf_rad_median": float(np.median(err)) if err.size else None, "frac_below_1e-5_rad": float((err < 1e-5).mean()) if err.size else None,
+                       "final_cost_median_of_solved": float(np.median(cost[gs < 2])) if (gs < 2).any() else None,
+                       "reference_logged_cost_band": "1.5e5 - 4e5, mean of 14 runs 1.964e5 (M200i/test.xlsx rows 5-19: the same script, MATLAB rand)"}
+print(json.dumps(res))
