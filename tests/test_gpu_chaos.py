@@ -5,10 +5,13 @@ Why this closes the gap.  On a chaotic problem the end-to-end comparison is mean
 > 1e-6 rad under a 1e-12 kick of x_init -- but that amplification builds up over the 5-20 outer iterations.  With the
 device's iterate u_{k-1} as the starting point only ONE iteration's amplification is in play, so a solver defect that shows
 up at iteration >= 2 (where warm starts, the certificate and the drift projection first run) cannot hide behind the chaos:
-u_k(device) must equal oracle_step(u_{k-1}(device)) to 1e-7 of |u_k| wherever the oracle's own single step is not itself
-kinked.  "Kinked" is again decided by the ORACLE alone: its single step moves by more than 1e-9 of |u_k| when u_{k-1} is
+u_k(device) must equal oracle_step(u_{k-1}(device)) to 1e-8 of |u_k| (1e-9 at the first iteration) wherever the oracle's own
+single step is not itself kinked.  "Kinked" is again decided by the ORACLE alone: its single step moves by more than 1e-9 of |u_k| when u_{k-1} is
 kicked by N(0, 1e-12^2) (a min-over-links switch, a clamp of distLinSeg or the near-zero surrogate of
-dist_arm_3D_200i_2.m:22-24 crossed inside the finite-difference stencil).  Kinked steps are counted, printed and capped.
+dist_arm_3D_200i_2.m:22-24 crossed inside the finite-difference stencil: amplification > 1e3 in ONE iteration -- these steps
+are what makes the problem chaotic, 8-50 % of its iterations).  On a kinked step the device must still be as close to the
+oracle as the oracle is to its kicked self (within 1e3 x that move).  Measured (MI355X, round 3): un-kinked steps max 2.7e-9 /
+1.3e-9 / 4.7e-9 (config 3 CFS / PSGCFS / config-4 shape), first iterations 5.5e-11 / 0 / 6.8e-10.
 
 The u log comes from cfs_debug_log_u (both solvers; the solve itself is unchanged: asserted bit for bit).
 """
@@ -21,7 +24,8 @@ from helpers import oracle_one_step
 
 pytestmark = pytest.mark.gpu
 
-ONE_STEP_TOL = 1e-7       # |u_k(device) - oracle_step(u_{k-1}(device))|_inf / |u_k|_inf on un-kinked steps
+ONE_STEP_TOL = 1e-8       # |u_k(device) - oracle_step(u_{k-1}(device))|_inf / |u_k|_inf on un-kinked steps
+FIRST_STEP_TOL = 1e-9     # the same at iteration 1 (identical linearisation point, no warm start, no amplification yet)
 KINK = 1e-9               # the oracle's own single step moves by more than this (relative) under a 1e-12 kick
 
 
@@ -99,7 +103,9 @@ def _check(gpu, O, s, bt, mode, chaotic, tag):
           f"kinked steps: median err {np.median(err[kink]) if kink.any() else 0:.1e}")
     bad = [(int(idx[steps[i][0]]), steps[i][1], float(err[i]), float(sens[i])) for i in np.nonzero(~kink & ~(err <= ONE_STEP_TOL))[0]]
     assert not bad, bad
-    assert kink.mean() <= 0.25, kink.mean()
+    bad1 = [(int(idx[steps[i][0]]), float(err[i])) for i in np.nonzero(first & ~kink & ~(err <= FIRST_STEP_TOL))[0]]
+    assert not bad1, bad1
+    assert (~kink).sum() >= 0.4 * len(steps)                          # most iterations, even of these problems, are ordinary
     # on a kinked step the device must still be AS CLOSE to the oracle as the oracle is to itself (within 1e3 x its own move)
     worse = [(int(idx[steps[i][0]]), steps[i][1], float(err[i]), float(sens[i])) for i in np.nonzero(kink & np.isfinite(sens) & ~(err <= np.maximum(ONE_STEP_TOL, 1e3 * sens)))[0]]
     assert len(worse) <= 0.02 * len(steps), worse

@@ -90,7 +90,8 @@ def test_device_rrt_trees_match_oracle_node_for_node(gpu, solver):
     for r in ok[:8]:                                                                       # properties of a found route
         np.testing.assert_array_equal(r.route[:, 0], s.x0)
         assert np.all(np.abs(r.route[:, -1] - g) < region_g)
-        np.testing.assert_allclose(np.linalg.norm(np.diff(r.route, axis=1), axis=0), 0.1, atol=1e-12)
+        if solver == "RRT":                                                                # RRT* re-parents: its edges may be longer
+            np.testing.assert_allclose(np.linalg.norm(np.diff(r.route, axis=1), axis=0), 0.1, atol=1e-12)
     # numpy Generators give the same trees as their pre-drawn streams (Generator.random(n) is the concatenation of n draws)
     again = planner.grow([np.random.default_rng(1000 + sd) for sd in range(4)])
     for t in range(4):
