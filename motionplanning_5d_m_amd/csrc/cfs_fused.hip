@@ -48,6 +48,9 @@ constexpr int CERT_AT = CFS_CERT_AT;    // main-loop steps of a QP before the st
 #ifndef CFS_TU
 #define CFS_TU 8                         // tail columns of P / global rows of Y loaded per batch (independent loads in flight)
 #endif
+#ifndef CFS_LIN_UNROLL
+#define CFS_LIN_UNROLL 0                 // 1: two segment pairs per thread in flight in the distance loops of the linearisation
+#endif
 #ifndef CFS_PR
 #define CFS_PR 64                        // columns of each inverse-Gram row kept in registers
 #endif
@@ -152,6 +155,21 @@ __device__ __forceinline__ void block_sum4(double &a, double &b, double &c, doub
     b = (red[4] + red[5]) + (red[6] + red[7]);
     c = (red[8] + red[9]) + (red[10] + red[11]);
     d = (red[12] + red[13]) + (red[14] + red[15]);
+}
+
+// three sums through one exchange: a and b combined pairwise as block_sum4 does, c left to right as block_sum does (each keeps
+// the rounding it had when it was reduced on its own)
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *red, int tid)
+{
+    const double sa = wave_add(a), sb = wave_add(b), sc = wave_add(c);
+    if ((tid & 63) == 0) { const int w = tid >> 6; red[w] = sa; red[4 + w] = sb; red[8 + w] = sc; }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+    double t = red[8];
+#pragma unroll
+    for (int w = 1; w < FT / 64; ++w) t += red[8 + w];
+    c = t;
 }
 
 // inclusive prefix sum over the 64 lanes of a wavefront (DPP row shifts + row broadcasts)
@@ -391,7 +409,7 @@ struct PRow {
 };
 
 struct FusedLayout {      // LDS offsets in doubles, computed identically on host and device
-    int rb, ob, x, u, qu, g, rhs, xs, wb, zb, d, r, rho, lam, prow, act, fre, prev, flag, slot, code, red, small, mx, racc, cost, ptail, lin, y, total_fixed;
+    int rb, ob, x, u, qu, g, rhs, xs, up, wb, zb, d, r, rho, lam, prow, act, fre, prev, flag, slot, code, red, small, mx, racc, cost, ptail, lin, y, total_fixed;
 };
 __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int QB, int PR)
 {
@@ -406,6 +424,7 @@ __host__ __device__ inline FusedLayout fused_layout(int NJ, int H, int nobs, int
     L.g = o; o += nobs * HN;
     L.rhs = o; o += nobs * H;
     L.xs = o; o += 3 * HN;
+    L.up = o; o += HN;                     // Bpos*u of the linearisation point (right sides of the collision rows)
     L.act = o; o += (QB + 1) / 2;
     L.fre = o; o += (QB + 1) / 2;          // stack of freed slots
     L.prev = o; o += (QB + 1) / 2;         // active rows (codes per slot) at the end of the previous QP: the warm start
@@ -446,7 +465,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     const FusedLayout L = fused_layout(NJ, H, nobs, QB, PR);
     DevRobot *rb = reinterpret_cast<DevRobot *>(lds + L.rb);
     double *s_ob = lds + L.ob, *s_x = lds + L.x, *s_u = lds + L.u, *s_qu = lds + L.qu, *s_g = lds + L.g;
-    double *s_rhs = lds + L.rhs, *xs = lds + L.xs, *wb = lds + L.wb, *zb = lds + L.zb;
+    double *s_rhs = lds + L.rhs, *xs = lds + L.xs, *s_up = lds + L.up, *wb = lds + L.wb, *zb = lds + L.zb;
     double *s_d = lds + L.d, *s_r = lds + L.r, *s_rho = lds + L.rho, *s_lam = lds + L.lam, *s_prow = lds + L.prow;
     int *s_act = reinterpret_cast<int *>(lds + L.act);
     int *s_free = reinterpret_cast<int *>(lds + L.fre);
@@ -534,6 +553,40 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
 
     while (!done) {
         // =========================================================================================
+        // Start vector of this iteration's QP and the two rollouts it needs -- Bpos*u for the right sides of the collision rows
+        // (CFS_FANUC.m:119-120) and (x, Bvel x, Bpos x) of the start point -- depend only on the previous iterate, not on the
+        // linearisation: they are computed in four steps that ride along with the first four phases of the linearisation
+        // (no barrier of their own; `prep(ph)` below), or in four phases of their own when there is nothing to ride on.
+        // =========================================================================================
+        bool skip = false;
+        if (P.piece == 0 && P.mode == CFS_MODE_PSGCFS) {
+            skip = fabs(cost_new - cost_old) < 1e-4;        // stop_inner, MAX_I_ITER = 1 (PSGCFS_FANUC.m:136-142)
+            if (!skip) cost_old = cost_new;                 // PSGCFS_FANUC.m:89
+        } else if (P.piece == 0) cost_old = cost_new;       // CFS_FANUC.m:67
+        const int noise_row_now = noise_row;
+        if (P.piece == 0 && P.mode == CFS_MODE_PSGCFS && !skip) ++noise_row;
+        auto prep = [&](int ph) {
+            if (P.piece == 1) return;
+            if (ph == 0) { for (int k = tid; k < HN; k += FT) xs[k] = s_u[k]; }
+            else if (ph == 1) roll_lds<NJ>(xs, H, dt, tid);
+            else if (ph == 2) {
+                const bool psg = P.piece == 0 && P.mode == CFS_MODE_PSGCFS;
+                const double sc = (double)iter_O * (double)iter_O + 1.0;
+                const bool have = P.noise != nullptr && noise_row_now < P.noise_rows;
+                for (int k = tid; k < HN; k += FT) {
+                    s_up[k] = xs[2 * HN + k];
+                    double v;
+                    if (psg && skip) v = s_u[k];            // no step: x_ is the rollout of the unchanged u
+                    else if (psg) {
+                        const double nz = have ? P.noise[((size_t)b * P.noise_rows + noise_row_now) * nn + k] : 0.0;
+                        v = s_u[k] - P.alpha * ((s_qu[k] + P.ff[(size_t)b * nn + k]) + 10.0 * nz / sc);   // PSGCFS_FANUC.m:109
+                    } else v = P.x0[(size_t)b * nn + k];    // CFS: -H^{-1} ff; cfs_qp: the caller's start point
+                    xs[k] = v;
+                }
+            } else roll_lds<NJ>(xs, H, dt, tid);
+        };
+        bool prepped = false;
+        // =========================================================================================
         // get_con, distance half (CFS_FANUC.m:110-118): dist -> s_rhs, Diff -> s_g
         // =========================================================================================
         if (nseg > 0) {
@@ -546,6 +599,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             int *s_cnt = s_free;                             // candidates per link (the QP's free-slot stack is idle here)
             for (int w0 = 0; w0 < H; w0 += W) {
                 const int Wc = min(W, H - w0);
+                if (w0 == 0) prep(0);
 #if CFS_ANGLE_ADD
                 const double ch = cos(FD_EPS / 2), sh = sin(FD_EPS / 2);
                 for (int e = tid; e < Wc * NJ; e += FT) {
@@ -593,15 +647,20 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         }
                     }
                 }
+                if (w0 == 0) prep(1);
                 __syncthreads();
                 STAMP(10);                                  // 10: sincos + link transforms
                 // Base-pose distance of every link (dist_arm_3D_200i_2.m:16-26), link index slow so the point /
                 // segment branch of distLinSeg is wave-uniform.
+#if CFS_LIN_UNROLL
+#pragma unroll 2
+#endif
                 for (int e = tid; e < NJ * Wc * nseg; e += FT) {
                     const int j = e % nseg, wi = (e / nseg) % Wc, k0 = e / (nseg * Wc);
                     s_bd[(wi * NJ + k0) * nseg + j] = seg_seg_dist(s_en + (wi * NVT + kvoff(k0 + 1)) * 6, s_ob + j * 6);
                 }
                 if (tid < NJ) s_cnt[tid] = 0;
+                if (w0 == 0) prep(2);
                 __syncthreads();
                 // num_jac only needs min over the links at 2nj shifted poses.  A link whose base distance exceeds
                 // max(min, 1e-4) by prune_tol can neither become the minimum nor reach the near-zero surrogate at any
@@ -621,6 +680,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
 #pragma unroll
                     for (int ev = 1; ev < NE; ++ev) s_dv[e * NE + ev] = INFINITY;
                 }
+                if (w0 == 0) { prep(3); prepped = true; }
                 __syncthreads();
                 STAMP(0);                                   // 0: base distances, candidate lists (+ the minima / differences below)
                 {
@@ -628,6 +688,9 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                     offs[0] = 0;
 #pragma unroll
                     for (int k1 = 1; k1 <= NJ; ++k1) offs[k1] = offs[k1 - 1] + s_cnt[k1 - 1] * 2 * k1;
+#if CFS_LIN_UNROLL
+#pragma unroll 2
+#endif
                     for (int e = tid; e < offs[NJ]; e += FT) {
                         int k1 = 1, ent = 0, v = 1;
 #pragma unroll
@@ -656,8 +719,13 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) s_g[(j * H + w0 + wi) * NJ + m] = (dev[2 * m + 1] - dev[2 * m + 2]) / FD_EPS;
                 }
-                __syncthreads();
+                // (no barrier between tiles: the next tile's first phase only writes its sin / cos table, which these differences do
+                // not read; its barrier covers both)
+                if (w0 + W >= H) __syncthreads();
             }
+        }
+        if (!prepped && P.piece != 1) {                     // nothing to ride on (mesh obstacles only, or the QP piece): four phases of their own
+            prep(0); __syncthreads(); prep(1); __syncthreads(); prep(2); __syncthreads(); prep(3); __syncthreads();
         }
 
         if (P.nmesh > 0) {   // rows of the mesh obstacles: linearised at this iterate by cfs_linearize_mesh_kernel (cfs_mesh.hip)
@@ -676,25 +744,6 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         // the QP of this outer iteration (CFS_FANUC.m:85 | PSGCFS_FANUC.m:106-128)
         // =========================================================================================
         STAMP(0);                                           // 0: linearisation
-        bool skip = false;
-        if (P.piece == 2) {                                 // cfs_qp: start point given (CFS: -H^{-1} lin, PSGCFS: u_)
-            for (int k = tid; k < HN; k += FT) xs[k] = P.x0[(size_t)b * nn + k];
-        } else if (P.mode == CFS_MODE_PSGCFS) {
-            skip = fabs(cost_new - cost_old) < 1e-4;        // stop_inner, MAX_I_ITER = 1 (PSGCFS_FANUC.m:136-142)
-            if (!skip) {
-                cost_old = cost_new;                        // PSGCFS_FANUC.m:89
-                const double sc = (double)iter_O * (double)iter_O + 1.0;
-                const bool have = P.noise != nullptr && noise_row < P.noise_rows;
-                for (int k = tid; k < HN; k += FT) {
-                    const double nz = have ? P.noise[((size_t)b * P.noise_rows + noise_row) * nn + k] : 0.0;
-                    xs[k] = s_u[k] - P.alpha * ((s_qu[k] + P.ff[(size_t)b * nn + k]) + 10.0 * nz / sc);   // :109
-                }
-                ++noise_row;
-            }
-        } else {
-            cost_old = cost_new;                            // CFS_FANUC.m:67
-            for (int k = tid; k < HN; k += FT) xs[k] = P.x0[(size_t)b * nn + k];
-        }
         int qp_status = QP_OK, iters = 0;
         int qhi = 0, nfree = 0;                             // slots in use: [0,qhi) minus the free stack
         int npolish = 0;
@@ -820,23 +869,18 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             }
         };
         if (!skip) {
-            // rhs = (d - margin) - Diff'*Bj(1:nj,:)*u   (CFS_FANUC.m:119-120), with Bpos*u from a rollout of u
-            for (int k = tid; k < HN; k += FT) wb[k] = s_u[k];
+            // rhs = (d - margin) - Diff'*Bj(1:nj,:)*u   (CFS_FANUC.m:119-120), with Bpos*u from the rollout of u (s_up)
             for (int e = tid; e < ncon; e += FT) { s_flag[e] = 0; s_slot[e] = 0; }
             Pr.zero(s_pt, tid, 0);
             if (tid < QB) { s_prev[tid] = s_act[tid]; s_d[tid] = 0.0; s_r[tid] = 0.0; s_rho[tid] = 0.0; s_prow[tid] = 0.0; s_lam[tid] = 0.0; s_act[tid] = -1; }
-            __syncthreads();
-            roll_lds<NJ>(wb, H, dt, tid);
-            roll_lds<NJ>(xs, H, dt, tid);
-            __syncthreads();
             for (int e = tid; e < nobs * H; e += FT) {
                 const int j = e / H, i = e - j * H;
                 double gp = 0.0;
 #pragma unroll
-                for (int c = 0; c < NJ; ++c) gp += s_g[e * NJ + c] * wb[2 * HN + i * NJ + c];
+                for (int c = 0; c < NJ; ++c) gp += s_g[e * NJ + c] * s_up[i * NJ + c];
                 s_rhs[e] = (s_rhs[e] - s_margin[j]) - gp;
             }
-            __syncthreads();
+            // (the sums of the infeasibility bound below share this phase: their exchange is the phase's one barrier)
             // Rigorous early infeasibility test.  At step 1 the iterate minimises the objective over a
             // subset of the constraints, so its objective value never exceeds the optimum, which in turn
             // is at most max{f(v): v in the box} <= f(x0) + lambda_max/2 (R + |x0|)^2, the box being
@@ -1115,6 +1159,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                 const int pc = cbest, ptype = pc >> 16, pi = (pc >> 8) & 0xff, pj = pc & 0xff;
                 const int pidx = ptype == CT_COL ? pj * H + pi : nobs * H + (ptype - 1) * HN + pi * NJ + pj;
                 double sp = sbest, lam_p = 0.0;
+                bool have_w = false;                        // wb = (w, Bvel w, Bpos w) of the entering row survives a partial step: gathered once per row
 
                 // step 2
                 for (;;) {
@@ -1130,9 +1175,12 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         __syncthreads();
                     }
                     if (!polish && !IDENT) {
+                    if (!have_w) {
                     gather_w(pc);                          // w = H^{-1} n_p with its rollouts
                     __syncthreads();
                     if (P.opt & 1) { roll_lds<NJ>(wb, H, dt, tid); __syncthreads(); }
+                    have_w = true;
+                    }
                     STAMP(3);                               // 3: w gather + rollout
                     spp = ndot<NJ>(pc, wb, s_g, H);
                     if (tid < qhi) s_d[tid] = myact >= 0 ? ndot<NJ>(myact, wb, s_g, H) : 0.0;
@@ -1316,13 +1364,10 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         // =========================================================================================
         // new u, rollout (CFS_FANUC.m:86-95), get_cost, store_result, iter_O++, stop_outer
         // =========================================================================================
-        if (skip) {
-            for (int k = tid; k < HN; k += FT) xs[k] = s_u[k];
-            __syncthreads();
-            roll_lds<NJ>(xs, H, dt, tid);
-            __syncthreads();
-        }
-        double du2 = 0.0, dx2 = 0.0;
+        // One phase, one barrier: the new state, the three sums (|du|^2, |dx|^2, cost) and the history.  xs = (u, Bvel u, Bpos u) is
+        // final here (a skipped PSG step left the rollout of the unchanged u in it), so everything below reads xs; s_u is refreshed
+        // at the end of the phase for the next iteration.
+        double du2 = 0.0, dx2 = 0.0, cpart = 0.0;
         for (int k = tid; k < HN; k += FT) {
             const int i = k / NJ, c = k - i * NJ;
             const double un = xs[k], e = s_u[k] - un;
@@ -1334,21 +1379,15 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             dx2 += (th - oth) * (th - oth) + (om - oom) * (om - oom);
             s_x[i * NS + c] = th;
             s_x[i * NS + NJ + c] = om;
+            s_u[k] = un;
+            if (P.u_log) P.u_log[((size_t)b * P.max_o_iter + (iter_O - 1)) * nn + k] = un;   // test aid: the iterate of every outer iteration
+            if (P.u_hist) P.u_hist[((size_t)b * P.max_o_iter + (iter_O - 1)) * nn + k] = un;
         }
-        { double z0 = 0.0, z1 = 0.0; block_sum4(du2, dx2, z0, z1, red, tid); }
-        for (int k = tid; k < HN; k += FT) s_u[k] = xs[k];
-        __syncthreads();
         // cost = 0.5*u'*QQ*u + ff'*u + caug (EVAL.m:52).  CFS: the stop test does not depend on it, so u is
         // logged and the whole cost history is one batched MFMA product after the solve (cfs_gemm.hip).
         // PSGCFS: QQ*u is needed in the loop (stop_inner and the next gradient step).
         double cost = cost_new;
-        if (P.u_log)                                        // test aid: the iterate of every outer iteration, either solver
-            for (int k = tid; k < HN; k += FT) P.u_log[((size_t)b * P.max_o_iter + (iter_O - 1)) * nn + k] = s_u[k];
-        if (P.u_hist) {
-            for (int k = tid; k < HN; k += FT) P.u_hist[((size_t)b * P.max_o_iter + (iter_O - 1)) * nn + k] = s_u[k];
-            if (tid == 0) P.e_u_all[(size_t)b * P.max_o_iter + (iter_O - 1)] = sqrt(du2);
-        } else {
-            double cpart = 0.0;
+        if (!P.u_hist) {
             if (P.cost) {
                 // QQ = Baug'*Qaug*Baug + cR*(R+R') (main_FANUC.m:96-97) applied through its factors: with (p, v) = (Bpos u, Bvel u)
                 // already in xs, QQ*u = Bpos'(w_i (Qp p_i + qc v_i)) + Bvel'(w_i (qc p_i + Qv v_i)) + Rs u_i; Bpos', Bvel' are suffix
@@ -1380,10 +1419,10 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
                         const int k = lane * NJ + c;
                         double ru = 0.0;
 #pragma unroll
-                        for (int c2 = 0; c2 < NJ; ++c2) ru += ck->Rs[c + c2 * NJ] * s_u[lane * NJ + c2];
+                        for (int c2 = 0; c2 < NJ; ++c2) ru += ck->Rs[c + c2 * NJ] * xs[lane * NJ + c2];
                         const double sq = y + ru;
                         s_qu[k] = sq;
-                        cpart += s_u[k] * (0.5 * sq + P.ff[(size_t)b * nn + k]);
+                        cpart += xs[k] * (0.5 * sq + P.ff[(size_t)b * nn + k]);
                     }
                 }
             } else
@@ -1395,14 +1434,19 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
 #pragma unroll
                     for (int j = 0; j < CFS_MV_BATCH; ++j) ld[j] = P.QQ[k + (size_t)(c + j) * nn];
 #pragma unroll
-                    for (int j = 0; j < CFS_MV_BATCH; ++j) sa[j & 7] += ld[j] * s_u[c + j];
+                    for (int j = 0; j < CFS_MV_BATCH; ++j) sa[j & 7] += ld[j] * xs[c + j];
                 }
-                for (; c < HN; ++c) sa[0] += P.QQ[k + (size_t)c * nn] * s_u[c];
+                for (; c < HN; ++c) sa[0] += P.QQ[k + (size_t)c * nn] * xs[c];
                 const double s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
                 s_qu[k] = s;
-                cpart += s_u[k] * (0.5 * s + P.ff[(size_t)b * nn + k]);
+                cpart += xs[k] * (0.5 * s + P.ff[(size_t)b * nn + k]);
             }
-            cost = block_sum(cpart, red, tid) + P.caug[b];
+        }
+        block_sum3(du2, dx2, cpart, red, tid);
+        if (P.u_hist) {
+            if (tid == 0) P.e_u_all[(size_t)b * P.max_o_iter + (iter_O - 1)] = sqrt(du2);
+        } else {
+            cost = cpart + P.caug[b];
             if (tid == 0) {
                 const size_t o = (size_t)b * P.max_o_iter + (iter_O - 1);
                 P.cost_all[o] = cost;                              // EVAL.m:56-58
