@@ -177,7 +177,8 @@ struct cfs_problem {
     DevBuf<double> Mr[6];   // rollouts (Bvel*, Bpos*) of the columns of M1n, M2n, Hq
     // workspace (max_batch problems)
     DevBuf<double> x0, qu, dist, grad, Yg, Pt, u_hist, qu_hist;
-    DevBuf<int> noise_row, linkid;
+    DevBuf<int> noise_row, linkid, pool_flag;
+    int pool_n = 1;            // slots of the spill pool (Yg / Pt): one per workgroup that can be resident at once, never more than max_batch
     DevBuf<int> order, okey;   // launch order of the fused solver, automatic: violation count of the initial trajectory -> rank
     DevBuf<int> order_user;    // the caller's permutation (cfs_set_launch_order); a solve of another batch size falls back to the automatic order
     int n_cu = 256;            // compute units of the handle's device: a batch of at most n_cu problems starts all at once
@@ -209,7 +210,7 @@ struct cfs_problem {
         F1.release(); F2.release(); Cq.release(); cost.release();
         lim.release(); maxin.release(); margin.release(); x0.release(); qu.release(); dist.release();
         grad.release(); Yg.release(); noise_row.release(); order.release(); okey.release(); order_user.release();
-        linkid.release(); meshes_d.release(); st_cost.release(); st_done.release();
+        linkid.release(); pool_flag.release(); meshes_d.release(); st_cost.release(); st_done.release();
         m_ends.release(); m_base.release(); m_shift.release(); m_tri.release(); m_near.release(); m_upper.release();
         m_pd.release(); m_pnd.release(); m_pi.release();
         stamps.release(); trace.release(); u_log.release();
@@ -410,13 +411,17 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     p->nn = nn; p->ns = ns; p->nx = nx; p->lmax_vel = lmax_vel; p->lmax_H = lmax_H;
     build_dev_robot(desc->robot, p->hrobot);
     const size_t Bm = (size_t)desc->max_batch;
+    // spill pool (rows of Y beyond LDS, columns of P beyond the registers): one slot per workgroup that can be resident at once (two per
+    // compute unit), not one per problem of the batch -- config 4: 512 slots instead of 4 096 (0.4 GB instead of 3.4 GB per handle)
+    p->pool_n = (int)std::min<size_t>(Bm, (size_t)2 * p->n_cu);
+    const size_t Pn = (size_t)p->pool_n;
     hipError_t e = hipSetDevice(p->device);
 #define A_(buf, count) if (e == hipSuccess) e = p->buf.alloc(count)
     A_(rb, 1); A_(QQ, (size_t)nn * nn); A_(Hinv, (size_t)nn * nn);
     for (int m = 0; m < 6; ++m) { A_(Mr[m], (size_t)nn * nn); }
-    A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Bm * pt_stride(nn)); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
+    A_(M1n, (size_t)nn * nn); A_(M2n, (size_t)nn * nn); A_(Hq, (size_t)nn * nn); A_(Pt, Pn * pt_stride(nn)); A_(lim, nj); A_(maxin, nn); A_(margin, desc->nobs);
     A_(x0, Bm * nn); A_(qu, Bm * nn); A_(dist, Bm * desc->nobs * H); A_(grad, Bm * desc->nobs * H * nj);
-    A_(Yg, Bm * nn * nn);
+    A_(Yg, Pn * nn * nn); A_(pool_flag, Pn * 16);
     if (desc->mode == CFS_MODE_CFS) { A_(u_hist, Bm * (size_t)desc->MAX_O_ITER * nn); A_(qu_hist, Bm * (size_t)desc->MAX_O_ITER * nn); }
     A_(noise_row, Bm); A_(linkid, Bm * desc->nobs * H); A_(order, Bm); A_(okey, Bm); A_(order_user, Bm);
 #undef A_
@@ -427,6 +432,7 @@ int cfs_problem_create(const cfs_problem_desc *desc, cfs_problem **out)
     U_(lim, desc->lim, nj); U_(margin, desc->margin, desc->nobs);
     if (desc->mode == CFS_MODE_CFS) { U_(maxin, desc->MAX_input, nn); }
     else if (e == hipSuccess) e = hipMemset(p->maxin.p, 0, nn * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(p->pool_flag.p, 0, Pn * 16 * sizeof(int));
 #undef U_
     if (e != hipSuccess) {
         p->release_all();
@@ -573,7 +579,7 @@ static void fill_fused_family(const cfs_problem *p, FusedParams &fp, int B)
     fp.M1v = p->Mr[0].p; fp.M1p = p->Mr[1].p; fp.M2v = p->Mr[2].p; fp.M2p = p->Mr[3].p; fp.M3v = p->Mr[4].p; fp.M3p = p->Mr[5].p;
     fp.lim = p->lim.p; fp.maxin = p->maxin.p; fp.margin = p->margin.p;
     fp.x0 = p->x0.p;
-    fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(p->nn);
+    fp.Yg = p->Yg.p; fp.Pt = p->Pt.p; fp.pt_stride = pt_stride(p->nn); fp.pool_flag = p->pool_flag.p; fp.pool_n = p->pool_n;
     // kernel switch word: bit 0 = roll w = H^{-1} n_p out in LDS (the default since round 2: +2-4 % on config 3 CFS, a third of the
     // gather's L2 loads; CFS_DBG_GATHER_ROLLOUTS loads the precomputed rollouts of the family matrices instead), bit 1 = no
     // refinement, bit 3 = no warm start, bit 4 = no step-free certificate

@@ -103,9 +103,11 @@ struct FusedParams {
     const double *x0;            // CFS: -H^{-1} ff  (B x nn)
     double *u, *x_, *cost_all, *e_cost_all, *e_u_all;
     int *iter_O, *total_iter, *status;
-    double *Yg;                  // B x nn x nn: Y rows beyond the LDS capacity
-    double *Pt;                  // B x pt_stride: columns of the inverse Gram matrix beyond the register-resident ones
+    double *Yg;                  // pool_n x nn x nn: Y rows beyond the LDS capacity (one slot per workgroup that spills)
+    double *Pt;                  // pool_n x pt_stride: columns of the inverse Gram matrix beyond the register-resident ones
     size_t pt_stride;
+    int *pool_flag;              // pool_n: 0 free / 1 taken (atomicCAS by the workgroup that needs a slot)
+    int pool_n;
     double *dbg;                 // optional trace: 8 doubles per active-set step of problem dbg_b (developer aid)
     int dbg_b, dbg_cap;
     const int *order;            // optional launch order: workgroup w solves problem order[w] (a permutation of 0..B-1); NULL = identity

@@ -479,10 +479,31 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     double *s_lim = lds + L.small, *s_v0 = s_lim + NJ, *s_th0 = s_v0 + NJ, *s_margin = s_th0 + 2 * NJ;
     double *s_mx = lds + L.mx;
     double *s_racc = lds + L.racc;
-    double *s_pt = P.Pt + (size_t)b * P.pt_stride;        // columns [PR,QB) of P, [b-PR][a]
+    // Spill space (columns [PR,QB) of P as [b-PR][a], rows of Y beyond the LDS capacity) comes from a POOL of P.pool_n slots, one per
+    // workgroup that can be resident at once (2 per compute unit), not one per problem of the batch: a workgroup takes a free slot
+    // when it starts (one atomicCAS by thread 0) and gives it back when it ends.  With fewer slots than resident workgroups a
+    // workgroup would only wait for another one to finish (holders never wait for anything).
+    int pool_slot;
+    {
+        int *pubp = reinterpret_cast<int *>(red_base + 63);
+        if (tid == 0) {
+            // flags are 64 bytes apart (one L2 line each: atomics on neighbours do not serialise); the probe starts at a hash of the
+            // workgroup index so that workgroups starting together do not walk the same run of taken slots
+            int sidx = (int)(((blockIdx.x * 0x9E3779B1u) >> 8) % (unsigned)P.pool_n);
+            while (atomicCAS(&P.pool_flag[sidx * 16], 0, 1) != 0) { sidx = sidx + 1 == P.pool_n ? 0 : sidx + 1; __builtin_amdgcn_s_sleep(2); }
+            pubp[0] = sidx;
+        }
+        __syncthreads();
+        pool_slot = pubp[0];
+    }
+    double *const s_pt = P.Pt + (size_t)pool_slot * P.pt_stride;
     double *s_Y = lds + L.y;                        // QY rows of HN doubles; linearisation scratch in between
     const int QY = P.qy;
-    double *Yg = P.Yg + (size_t)b * nn * nn;
+    double *const Yg = P.Yg + (size_t)pool_slot * nn * nn;
+    auto drop_pool = [&]() {
+        __syncthreads();                                   // every thread is done with the slot
+        if (tid == 0) { __threadfence(); atomicExch(&P.pool_flag[pool_slot * 16], 0); }
+    };
     const int ncon = nobs * H + (P.has_bounds ? 4 : 2) * HN;
     const int maxit = 8 * nn + 200;                  // the oracle's longest certificates take ~2 nn steps
     // constraint codes never change: decoded once into LDS (no integer divisions in the step loop)
@@ -738,7 +759,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             for (int e = tid; e < nobs * H; e += FT) P.dump_dist[(size_t)b * nobs * H + e] = s_rhs[e];
             for (int e = tid; e < nobs * HN; e += FT) P.dump_grad[(size_t)b * nobs * HN + e] = s_g[e];
         }
-        if (P.piece == 1) return;
+        if (P.piece == 1) { drop_pool(); return; }
 
         // =========================================================================================
         // the QP of this outer iteration (CFS_FANUC.m:85 | PSGCFS_FANUC.m:106-128)
@@ -987,7 +1008,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // multipliers are >= 0): build P for the previous rows -- Gram products only, wavefront 0 alone, no scan, no combine,
             // no block barrier --, take lambda = -P s(x0), drop rows with lambda <= 0 until none is left, set x = x0 + N lambda.
             // The optimum is the same (strictly convex QP); what changes is the number of steps.
-            if (P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= min(64, P.warm_max > 0 ? P.warm_max : min(PR, IDENT ? 64 : 24))) {   // rows beyond the register-resident columns would be built through L2 by one wavefront: slower than the cold steps (measured, config 3 CFS: limit 24 -> 3.61 ms per solve, 40 -> 3.72, 64 -> 3.97)
+            if (P.piece == 0 && !(P.opt & 8) && prev_q > 0 && prev_q <= min(64, P.warm_max > 0 ? P.warm_max : min(PR, IDENT ? 64 : 24))) {
                 int *pub = reinterpret_cast<int *>(red_base + 62);
                 int q = 0;                                   // H = QQ: tracked by every thread (one barrier per row); H = I: by wavefront 0
                 for (int s0 = 0; s0 < (IDENT ? 1 : prev_q); ++s0) {
@@ -1353,6 +1374,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
         if (P.piece == 2) {
             for (int e = tid; e < HN; e += FT) P.u[(size_t)b * nn + e] = xs[e];
             if (tid == 0) { P.total_iter[b] = iters; P.status[b] = qp_status == QP_OK ? CFS_OK_CONVERGED : (qp_status == QP_INFEASIBLE ? CFS_QP_INFEASIBLE : CFS_NUMERIC); }
+            drop_pool();
             return;
         }
         if (qp_status != QP_OK) {        // the reference would crash here (CFS_FANUC.m:92); report instead
@@ -1463,6 +1485,7 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
     }
 
     // ---- results -----------------------------------------------------------------------------------
+    drop_pool();
     __syncthreads();
     for (int e = tid; e < HN; e += FT) P.u[(size_t)b * nn + e] = s_u[e];
     for (int e = tid; e < NX; e += FT) P.x_[(size_t)b * NX + e] = s_x[e];

@@ -257,3 +257,26 @@ def test_problem_create_from_weights(gpu, O, route_wp):
         slv = gpu.CFSBatch(sH, 1, [0.2], mode="CFS", max_batch=1, use_weights=True)
         print(f"[from_weights] nn = {5 * H}: cfs_problem_create_from_weights {1e3 * (time.perf_counter() - t0):.0f} ms")
         slv.close()
+
+
+def test_spill_pool_is_shared_and_given_back(gpu, wl):
+    """Rows of Y beyond the LDS capacity and columns of the inverse Gram matrix beyond the registers live in a pool of
+    min(max_batch, 2 x compute units) slots, one per workgroup that can be resident at once (csrc/cfs_fused.hip), not in
+    B x nn^2 of per-problem workspace.  600 copies of the batch's heaviest CFS problems (infeasibility proofs with 100+ active
+    rows: every one of them spills) share 512 slots; solved twice through the same handle (every slot was given back).  Every copy
+    must return the bits of the problem solved alone."""
+    s, bt = wl
+    base = gpu.CFSBatch(s, bt.nobs, bt.margin_cfs, mode="CFS", max_batch=B)
+    full = base.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs)
+    base.close()
+    heavy = np.argsort(-full.total_iter, kind="stable")[:4]
+    assert (full.total_iter[heavy] >= 200).all()
+    idx = np.tile(heavy, 150)
+    slv = gpu.CFSBatch(s, bt.nobs, bt.margin_cfs, mode="CFS", max_batch=idx.size)
+    slv.set_launch_order("identity")
+    got = slv.solve(bt.x_init[idx], bt.xR1[idx], bt.ff[idx], bt.caug[idx], bt.obs[idx])
+    again = slv.solve(bt.x_init[idx], bt.xR1[idx], bt.ff[idx], bt.caug[idx], bt.obs[idx])
+    slv.close()
+    for r in (got, again):
+        for k in ("u", "x_", "status", "iter_O", "total_iter"):
+            np.testing.assert_array_equal(getattr(r, k), getattr(full, k)[idx], err_msg=k)

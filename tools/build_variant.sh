@@ -5,6 +5,8 @@ set -e
 D=$(cd "$(dirname "$0")/../motionplanning_5d_m_amd/csrc" && pwd)
 T=$(mktemp -d)
 cp "$D"/*.hip "$D"/*.h "$D"/Makefile "$T"/
+if [ -n "$FUSED_SRC" ]; then cp "$FUSED_SRC" "$T/cfs_fused.hip"; fi   # A/B against another revision of the fused solver
+if [ -n "$DEVICE_H" ]; then cp "$DEVICE_H" "$T/cfs_device.h"; fi
 mkdir -p "$T/../include_stub"
 sed -i 's#\.\./\.\./include/cfs_hip.h#'"$D"'/../../include/cfs_hip.h#g' "$T"/Makefile "$T"/cfs_device.h
 for o in cfs_api cfs_geom cfs_gemm cfs_mesh cfs_chomp cfs_rrt; do cp "$D/$o.o" "$T/" 2>/dev/null && touch "$T/$o.o"; done

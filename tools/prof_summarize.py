@@ -32,6 +32,19 @@ def counters(d):
     return out, n
 
 
+def counters_of(d, kernel):
+    """{counter: (mean per launch, launches)} of kernel `kernel` in one pass"""
+    f = find(d, "counter_collection.csv")
+    if not f:
+        return {}
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if kernel in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: (sum(v.values()) / len(v), len(v)) for k, v in acc.items()}
+
+
 def main(tag):
     pmc = {"round": tag, "kernel": KERNEL,
            "command": "rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --mode <MODE> --steps 5 --warmup 2 --blocks 1 --streams 1 "
@@ -80,6 +93,20 @@ def main(tag):
             if g("TCC_HIT_sum") + g("TCC_MISS_sum"):
                 d["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
             mix["derived_" + mode] = d
+    for nm, dst in (("prof_stats_rrt", f"{tag}_rrt_bench_kernel_stats.csv"), ("prof_stats_mesh", f"{tag}_mesh_config5_reference_map_kernel_stats.csv")):
+        st = find(nm, "kernel_stats.csv")
+        if st:
+            shutil.copy(st, os.path.join(ROOT, "profiles", dst))
+    # the one MFMA site of the path: cfs_batched_gemv_kernel (-H^-1 ff before a CFS solve, QQ * logged u after it)
+    gm = counters_of("prof_pmc3_CFS", "cfs_batched_gemv_kernel")
+    if gm:
+        mops, n = gm.get("SQ_INSTS_VALU_MFMA_MOPS_F64", (0.0, 0))
+        fma, _ = gm.get("SQ_INSTS_VALU_FMA_F64", (0.0, 0))
+        mix["mfma_site"] = {"kernel": "cfs_batched_gemv_kernel (v_mfma_f64_16x16x4_f64)", "launches_counted": n,
+                            "SQ_INSTS_VALU_MFMA_MOPS_F64_per_launch": mops, "SQ_INSTS_VALU_FMA_F64_per_launch": fma,
+                            "SQ_INSTS_VALU_MFMA_MOPS_F64_of_the_fused_kernel": mix["per_launch"].get("CFS", {}).get("SQ_INSTS_VALU_MFMA_MOPS_F64"),
+                            "note": "MFMA is nominal on this path: the two batched products (nn x nn times nn x B) are the only GEMM-shaped work; "
+                                    "constraint rows are structured and never form a dense matrix (DESIGN.md section 4.2)"}
     json.dump(pmc, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
     shutil.copy(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), os.path.join(ROOT, "profiles", "pmc_latest.json"))
     json.dump(mix, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_instmix.json"), "w"), indent=1)

@@ -4,7 +4,7 @@
 #   counters: one --pmc pass per group per solver, serial launches (--streams 1), no trace domains
 # usage: bash tools/profile_round.sh <tag>      (then, in the build container: python tools/prof_summarize.py <tag>)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -23,3 +23,8 @@ for MODE in PSGCFS CFS; do
     echo "pmc group $i $MODE done"
   done
 done
+# RRT kernel and the config-5 reference map: kernel stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_rrt -- python3 $ROOT/tests/tools/rrt_bench.py --steps 5 --rounds 1 > $OUT/prof_stats_rrt.log 2>&1
+echo "stats rrt done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_mesh -- python3 $ROOT/bench.py --config 5 --map reference --steps 5 --warmup 1 --blocks 1 --streams 1 --no-cpu-baseline > $OUT/prof_stats_mesh.log 2>&1
+echo "stats mesh done"
