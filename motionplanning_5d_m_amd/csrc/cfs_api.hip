@@ -640,6 +640,9 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
 static int enqueue_solve(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, hipStream_t s, hipEvent_t *e4)
 {
     const int B = in->B, nj = p->d.njoint, nn = p->nn, K = p->d.MAX_O_ITER;
+    // every workgroup gives its spill slot back on every exit path; clearing the flags anyway costs one tiny memset per solve and
+    // means a launch can never wait for a slot that an aborted predecessor left taken
+    HIPCHK(hipMemsetAsync(p->pool_flag.p, 0, (size_t)p->pool_n * 16 * sizeof(int), s));
     if (p->prof) HIPCHK(hipEventRecord(e4[0], s));
     if (p->d.mode == CFS_MODE_CFS) {     // unconstrained minimiser -H^{-1} ff (MFMA), constant over the outer loop
         GemvParams g;
