@@ -337,3 +337,28 @@ def test_eval_get_cost_b_and_get_cost(gpu, O, route_wp):
             wc = 0.5 * wu @ s.QQ @ wu + ff[b] @ wu + caug[b]
             assert abs(cb[b] - wc) <= 1e-10 * abs(caug[b])
         slv.close()
+
+
+def test_rollout_against_the_reference_own_stored_trajectory(gpu):
+    """The reference's stored (u -> x_) pair (data/M16_ref_2.mat:uref, data/good_xori.mat:xuori; fixture
+    tests/golden/reference_rollout_M16.npz, see tests/test_oracle_golden.py) through the PRODUCT: a CFS_FANUC problem whose QP
+    has H = I, f = -uref and no active constraint (one far obstacle, wide limits), so that the fused kernel's QP returns
+    u = uref and its rollout (prefix sums in LDS, not the literal recurrence of Lib/CFS_FANUC.m:90-94) must land on the
+    trajectory MATLAB saved.  Bar: u exact, x_ within 1e-13 rad of the stored one (the two summation orders differ by
+    a few ulp of |x| <= 2.6)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_rollout_M16.npz"))
+    uref, xuori = g["uref"], g["xuori"]
+    robot = gpu.robotproperty2("M16iB")
+    th0, th1 = xuori[:5], xuori[240:245]
+    s = gpu.build_sys_info(robot, 5, 24, th0, th1, gpu.line_reference(th0, th1, 24), Qp=np.eye(5), Qv=np.eye(5), Rblk=np.eye(5), cR=1.0,
+                           lim=np.ones(5), max_input_blk=np.full(5, 0.5), epsilon_O=1e-12, MAX_O_ITER=1)
+    s.QQ = s.Qaug = np.eye(120)
+    s.ff = s.paug = -uref
+    s.xR = xuori[:10].reshape(10, 1).copy()
+    del s.weights                                                      # a dense family: QQ is not what the weights would assemble
+    far = [gpu.cylinder((40000, 40000, 1), (40000, 40000, 900), 0.2, 0.25)]
+    got = gpu.CFS_FANUC(far, s, "M16iB").optimizer()
+    assert got.status == 1 and got.iter_O == 2                          # one iteration, then MAX_O_ITER
+    np.testing.assert_array_equal(got.u, uref)
+    assert np.abs(got.x_ - xuori[10:]).max() < 1e-13, np.abs(got.x_ - xuori[10:]).max()

@@ -69,3 +69,25 @@ def test_first_iteration_fixtures(O, golden, route_wp):
         np.testing.assert_array_equal(lid, golden[name + "/linkid1"])
         np.testing.assert_array_equal(grad, golden[name + "/grad1"])
         np.testing.assert_allclose([A.sum(), np.abs(A).sum()], golden[name + "/Ainq1_sum"], rtol=1e-13)
+
+
+def test_rollout_reproduces_the_reference_own_stored_trajectory(O):
+    """The one stored OUTPUT of the reference's MATLAB runs that lies on the hot path: data/good_xori.mat:xuori (250 x 1) is the
+    state trajectory its legacy CFS script saved, data/M16_ref_2.mat:uref (120 x 1) the inputs that produced it
+    (M16iB/main_CFS.m:19-21, :162-169).  The oracle's rollout (Lib/CFS_FANUC.m:90-94: xR(:,i) = A*xR(:,i-1) + B*u(i-1) with the
+    double integrator of robotproperty2.m:136-139, delta_t = 0.5; x_ stacked [theta; omega] per waypoint, waypoint 0 dropped:
+    SURVEY N5) reproduces all 240 numbers BIT FOR BIT; data/M16_ref_2.mat:xref is the same trajectory with 75 angles shifted
+    by 2*pi.  Fixture: tests/golden/reference_rollout_M16.npz (data only; tests/golden/make_reference_rollout.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_rollout_M16.npz"))
+    uref, xref, xuori = g["uref"], g["xref"], g["xuori"]
+    assert uref.shape == (120,) and xref.shape == (250,) and xuori.shape == (250,)
+    dt = O.robotproperty2("M16iB").delta_t
+    assert dt == 0.5
+    x_ = O.rollout(24, 5, dt, xuori[:10], uref)
+    np.testing.assert_array_equal(x_, xuori[10:])                       # the reference's own MATLAB output, to the last bit
+    k = (xref - xuori) / (2 * np.pi)
+    assert np.abs(k - np.round(k)).max() < 1e-15 and int(np.abs(np.round(k)).sum()) == 75     # xref = xuori + 2 pi on 75 angles
+    # what the stored solution looks like: a feasible motion of the driver's problem class (velocity and input limits of main_FANUC.m)
+    X = xuori.reshape(25, 10)
+    assert np.abs(X[:, 5:]).max() < 1.0 and np.abs(uref).max() < 0.5
