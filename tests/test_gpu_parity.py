@@ -362,3 +362,27 @@ def test_rollout_against_the_reference_own_stored_trajectory(gpu):
     assert got.status == 1 and got.iter_O == 2                          # one iteration, then MAX_O_ITER
     np.testing.assert_array_equal(got.u, uref)
     assert np.abs(got.x_ - xuori[10:]).max() < 1e-13, np.abs(got.x_ - xuori[10:]).max()
+
+
+def test_forward_kinematics_against_the_reference_own_stored_capsules(gpu):
+    """The reference's stored FK output (figure/M16iBCapsules.mat:RoCap; fixture tests/golden/reference_capsules_M16iB.npz, see
+    tests/test_oracle_golden.py) through the PRODUCT: cfs_dist_arm's capsule end points for the M16iB at the stored pose, six
+    joints.  Eleven end points within 2e-15 m; the twelfth differs by the 0.01 m of a constant the reference has since edited
+    (robotproperty2.m:89), and with the constant as it was all twelve agree."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_capsules_M16iB.npz"))
+    want = g["p"].transpose(0, 2, 1)                                   # (link, end point, xyz)
+    th = np.array([[0.0, 1.5708, 0.0, 0.0, -np.pi / 2, np.pi]])
+    far = np.array([[40.0, 40.0, 0.0, 40.0, 40.0, 1.0]])
+    robot = gpu.robotproperty2("M16iB")
+    base = np.asarray(robot.base, float).ravel()
+    _, _, pos = gpu.dist_arm(robot, th, far, want_pos=True)
+    err = np.abs(pos[0] - base - want).max(axis=2)
+    legacy = np.zeros((6, 2), bool)
+    legacy[4, 1] = True
+    assert err[~legacy].max() < 2e-15, err
+    assert abs(err[4, 1] - 0.01) < 1e-12
+    old = copy.deepcopy(robot)
+    old.cap[4].p = np.array([[0.0, 0.0], [0.0, 0.0], [-0.05, 0.10]])
+    _, _, pos = gpu.dist_arm(old, th, far, want_pos=True)
+    assert np.abs(pos[0] - base - want).max() < 2e-15

@@ -91,3 +91,32 @@ def test_rollout_reproduces_the_reference_own_stored_trajectory(O):
     # what the stored solution looks like: a feasible motion of the driver's problem class (velocity and input limits of main_FANUC.m)
     X = xuori.reshape(25, 10)
     assert np.abs(X[:, 5:]).max() < 1.0 and np.abs(uref).max() < 0.5
+
+
+REF_CAPSULE_POSE = np.array([0.0, 1.5708, 0.0, 0.0, -np.pi / 2, np.pi])     # robotproperty2.m:67-72's theta column with theta_1 = 0
+
+
+def test_forward_kinematics_reproduces_the_reference_own_stored_capsules(O):
+    """figure/M16iBCapsules.mat:RoCap (robotproperty2.m:96 loads the file) is the stored OUTPUT of the reference's CapPos
+    (Lib/functions/CapPos.m:8-22) for the M16iB at the DH table's own pose with theta_1 = 0 and base = 0: six capsules, twelve
+    end points in world coordinates.  The oracle's FK lands on eleven of them to 1e-15 m; the twelfth (second end point of
+    capsule 5) is off by exactly 0.01 m along the capsule axis because robotproperty2.m:89 has since changed that constant
+    (`-0.05 0.110`; the stored capsule is 0.15 m long, i.e. it was 0.100).  Radii as robotproperty2.m:76-92.
+    Fixture: tests/golden/reference_capsules_M16iB.npz (data only; tests/golden/make_reference_capsules.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_capsules_M16iB.npz"))
+    want = g["p"].transpose(0, 2, 1)                                   # (link, end point, xyz)
+    rb = O.robotproperty2("M16iB")
+    np.testing.assert_array_equal(g["r"], np.asarray(rb.cap_r, float))
+    got = np.asarray(O.arm_pos(rb, REF_CAPSULE_POSE)) - np.asarray(rb.base).ravel()
+    err = np.abs(got - want).max(axis=2)                               # (link, end point)
+    legacy = np.zeros((6, 2), bool)
+    legacy[4, 1] = True
+    assert err[~legacy].max() < 2e-15, err
+    assert abs(err[4, 1] - 0.01) < 1e-12 and abs(np.linalg.norm(want[4, 1] - want[4, 0]) - 0.15) < 1e-6
+    # with the constant as it was when the file was written, all twelve
+    import copy
+    rb_old = copy.deepcopy(rb)
+    rb_old.cap[4] = np.array([[0.0, 0.0], [0.0, 0.0], [-0.05, 0.10]])
+    got = np.asarray(O.arm_pos(rb_old, REF_CAPSULE_POSE)) - np.asarray(rb.base).ravel()
+    assert np.abs(got - want).max() < 2e-15

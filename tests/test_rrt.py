@@ -175,7 +175,8 @@ def test_parallel_rrt_then_cfs_pipeline(gpu):
     """RRTstar_CFS.m end to end with its own start, goal, obstacles and weights: s_Parallel_rrt -> cubic resampling to 41
     points -> CFS_FANUC.optimizer().  The only whole-loop numbers the reference holds are its hand-kept run logs of exactly
     this script (M200i/test.xlsx rows 5-18 and row 19, M200i/test.csv:1; RRT is random, so they are a band, not a value):
-    final cost eval.cost_new between 1.5e5 and 4e5 (mean of 14 runs 1.964e5), iter_O - 1 between 2 and 21.  Runs whose
+    final cost eval.cost_new between 1.5e5 and 4e5 (mean of 14 runs 1.964e5), iter_O - 1 between 2 and 21; Lib/test.xlsx rows
+    2-20 log 19 more runs of it: final cost 1.876e5 - 2.036e5, median 1.949e5, 8 - 21 iterations.  Runs whose
     linearisation becomes infeasible have no counterpart there (the reference ignores quadprog's exitflag and would crash at
     Lib/CFS_FANUC.m:92): they are reported, and must stay a minority."""
     pobs, s, g, region_g, region_s, off = gpu.RRTstar_problem()
@@ -199,3 +200,4 @@ def test_parallel_rrt_then_cfs_pipeline(gpu):
     assert len(costs) >= 2
     assert all(1.5e5 <= c <= 4e5 for c in costs), costs                 # M200i/test.xlsx col C rows 5-18
     assert all(2 <= k <= 21 for k in its), its                           # col E minus iter_rrt = 1
+    assert 1.85e5 <= float(np.median(costs)) <= 2.05e5, costs            # Lib/test.xlsx col C rows 2-20: 1.876e5 - 2.036e5
