@@ -56,4 +56,4 @@ for b in bad:
     nbox = int((np.abs(r.ineqlin.marginals[Ac.shape[0]:]) > 1e-9).sum()); nbnd = int((np.abs(r.lower.marginals[:nn]) + np.abs(r.upper.marginals[:nn]) > 1e-9).sum())
     out.append(dict(b=b, k=k, t=float(r.fun), rows=rows, nvel=nbox, nbnd=nbnd))
     print(b, "iter", k, "t* %.3e" % r.fun, "collision rows", rows, "vel rows", nbox, "bound rows", nbnd, flush=True)
-json.dump(out, open("/tmp/study/infeasible.json", "w"))
+json.dump(out, open("gpurun_out/study/infeasible.json", "w"))
