@@ -86,6 +86,29 @@ def test_batch_invariance_and_permutation(gpu, wl):
 
 
 @pytest.mark.parametrize("mode", ["CFS", "PSGCFS"])
+def test_batch_of_32768_equals_its_1024_problem_tiles(gpu, wl, mode):
+    """Sized for the card: config 3's 1024 problems tiled 32 times into ONE solve of 32 768 problems (64-bit offsets, the launch
+    order pre-pass over the whole batch, the spill pool shared by 32 768 workgroups) returns, tile by tile, the bits of the
+    1024-problem solve."""
+    s, bt = wl
+    T = 32
+    margin = bt.margin_cfs if mode == "CFS" else bt.margin_psg
+    noise = bt.noise if mode == "PSGCFS" else None
+    small = gpu.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=B)
+    ref = small.solve(bt.x_init, bt.xR1, bt.ff, bt.caug, bt.obs, noise=noise)
+    small.close()
+    big = gpu.CFSBatch(s, bt.nobs, margin, mode=mode, max_batch=T * B)
+    tile = lambda a: np.concatenate([a] * T, axis=0)  # noqa: E731
+    got = big.solve(tile(bt.x_init), tile(bt.xR1), tile(bt.ff), tile(bt.caug), tile(bt.obs), noise=None if noise is None else tile(noise))
+    big.close()
+    for k in ("status", "iter_O", "total_iter", "u", "x_", "cost_all", "e_u_all"):
+        a = getattr(got, k).reshape((T, B) + getattr(ref, k).shape[1:])
+        for tt in (0, 1, T // 2, T - 1):
+            np.testing.assert_array_equal(a[tt], getattr(ref, k), err_msg=f"{k}, tile {tt}")
+        assert (a == a[0]).all(), k
+
+
+@pytest.mark.parametrize("mode", ["CFS", "PSGCFS"])
 def test_launch_order_does_not_change_results(gpu, wl, mode):
     """cfs_set_launch_order: automatic (violation count of the initial trajectory, the default above 256 problems), identity
     and a given permutation all return the same bits; a non-permutation is refused."""
