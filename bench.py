@@ -54,6 +54,7 @@ import time
 # the runtime when it initialises, i.e. before torch touches the GPU).  Measured, CFS 8 in flight: 4 queues 2.5-3.1 ms per
 # solve depending on which streams collide, 16 queues 2.05 ms.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool: RCCL across processes needs it (already exported on the boxes)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
