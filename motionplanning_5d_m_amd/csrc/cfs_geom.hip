@@ -54,21 +54,27 @@ __global__ __launch_bounds__(256) void cfs_dist_arm_kernel(DistArmParams P)
 }
 
 // key[b] = number of (waypoint, line obstacle) pairs of problem b whose clearance on the initial trajectory is below the
-// margin; one workgroup per problem, one waypoint per thread
-__global__ __launch_bounds__(128) void cfs_order_key_kernel(OrderParams P)
+// margin.  Eight problems per 256-thread workgroup, 32 lanes per problem, one waypoint per lane: the pre-pass runs on the
+// solve's stream while ANOTHER solve's fused kernel holds every compute unit (two workgroups of 256 VGPRs per lane fill
+// the register file), so each of its workgroups waits for a fused workgroup to retire -- 128 workgroups instead of 1 024 per
+// batch of 1 024 (measured in flight: 0.28 ms -> see DESIGN.md section 5).
+constexpr int ORDER_PB = 8;
+__global__ __launch_bounds__(256) void cfs_order_key_kernel(OrderParams P)
 {
     __shared__ __attribute__((aligned(16))) double s_rb[sizeof(DevRobot) / 8];
-    __shared__ int s_cnt;
+    __shared__ int s_cnt[ORDER_PB];
     {
         const double *src = reinterpret_cast<const double *>(P.rb);
         for (int e = threadIdx.x; e < (int)(sizeof(DevRobot) / 8); e += blockDim.x) s_rb[e] = src[e];
     }
-    if (threadIdx.x == 0) s_cnt = 0;
+    if (threadIdx.x < ORDER_PB) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const DevRobot *rb = reinterpret_cast<const DevRobot *>(s_rb);
-    const int b = blockIdx.x, ns = 2 * P.nj;
+    const int sub = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const int b = blockIdx.x * ORDER_PB + sub, ns = 2 * P.nj;
     int cnt = 0;
-    for (int i = threadIdx.x; i < P.H; i += blockDim.x) {
+    if (b < P.B)
+    for (int i = lane; i < P.H; i += 32) {
         double ends[CFS_MAX_LINKS * 6];
         double M[12], Mn[12];
         for (int k = 0; k < P.nj; ++k) {
@@ -86,9 +92,9 @@ __global__ __launch_bounds__(128) void cfs_order_key_kernel(OrderParams P)
             cnt += d < P.margin[j];
         }
     }
-    if (cnt) atomicAdd(&s_cnt, cnt);
+    if (cnt) atomicAdd(&s_cnt[sub], cnt);
     __syncthreads();
-    if (threadIdx.x == 0) P.key[b] = s_cnt;
+    if (lane == 0 && b < P.B) P.key[b] = s_cnt[sub];
 }
 
 // order = problems by descending key, ties by index (a stable rank: no atomics, the same order on every run)
@@ -161,7 +167,7 @@ void launch_dist_arm(const DistArmParams &p, hipStream_t s)
 
 void launch_order(const OrderParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(cfs_order_key_kernel, dim3(p.B), dim3(128), 0, s, p);
+    hipLaunchKernelGGL(cfs_order_key_kernel, dim3((p.B + ORDER_PB - 1) / ORDER_PB), dim3(256), 0, s, p);
     hipLaunchKernelGGL(cfs_order_rank_kernel, dim3((p.B + 255) / 256), dim3(256), 0, s, p);
 }
 
