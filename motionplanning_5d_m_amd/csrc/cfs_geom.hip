@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void cfs_dist_arm_kernel(DistArmParams P)
 // margin.  Eight problems per 256-thread workgroup, 32 lanes per problem, one waypoint per lane: the pre-pass runs on the
 // solve's stream while ANOTHER solve's fused kernel holds every compute unit (two workgroups of 256 VGPRs per lane fill
 // the register file), so each of its workgroups waits for a fused workgroup to retire -- 128 workgroups instead of 1 024 per
-// batch of 1 024 (measured in flight: 0.28 ms -> see DESIGN.md section 5).
+// batch of 1 024: config 3 PSGCFS 1.467 -> 1.451 ms per solve, CFS 1.598 -> 1.586 (same-call A/B, two rounds; 16 grid-striding
+// workgroups instead: PSGCFS 1.489, CFS 1.578 -- the longer pre-pass costs the short solve more than the waiting saved).
 constexpr int ORDER_PB = 8;
 __global__ __launch_bounds__(256) void cfs_order_key_kernel(OrderParams P)
 {
