@@ -178,6 +178,7 @@ struct cfs_problem {
     // workspace (max_batch problems)
     DevBuf<double> x0, qu, dist, grad, Yg, Pt, u_hist, qu_hist;
     DevBuf<int> noise_row, linkid, pool_flag;
+    bool pool_dirty = false;   // a solve of this handle failed to enqueue: clear the spill-pool flags before the next one
     int pool_n = 1;            // slots of the spill pool (Yg / Pt): one per workgroup that can be resident at once, never more than max_batch
     DevBuf<int> order, okey;   // launch order of the fused solver, automatic: violation count of the initial trajectory -> rank
     DevBuf<int> order_user;    // the caller's permutation (cfs_set_launch_order); a solve of another batch size falls back to the automatic order
@@ -630,7 +631,10 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
             if (!p->ev_free.empty()) { e4[k] = p->ev_free.back(); p->ev_free.pop_back(); }
             else if (hipEventCreate(&e4[k]) != hipSuccess) { e4[k] = nullptr; rc = fail(CFS_ERR_HIP, "hipEventCreate failed"); }
         }
-    if (rc == CFS_SUCCESS) rc = enqueue_solve(p, in, out, s, e4);
+    if (rc == CFS_SUCCESS) {
+        rc = enqueue_solve(p, in, out, s, e4);
+        if (rc != CFS_SUCCESS) p->pool_dirty = true;
+    }
     if (p->prof)                         // recorded events are read by cfs_profile_read; after an error they go back to the pool
         for (int k = 0; k < 4; ++k)
             if (e4[k]) (rc == CFS_SUCCESS ? p->ev : p->ev_free).push_back(e4[k]);
@@ -640,9 +644,13 @@ int cfs_solve_batch_device(cfs_problem *p, const cfs_batch_in *in, const cfs_bat
 static int enqueue_solve(cfs_problem *p, const cfs_batch_in *in, const cfs_batch_out *out, hipStream_t s, hipEvent_t *e4)
 {
     const int B = in->B, nj = p->d.njoint, nn = p->nn, K = p->d.MAX_O_ITER;
-    // every workgroup gives its spill slot back on every exit path; clearing the flags anyway costs one tiny memset per solve and
-    // means a launch can never wait for a slot that an aborted predecessor left taken
-    HIPCHK(hipMemsetAsync(p->pool_flag.p, 0, (size_t)p->pool_n * 16 * sizeof(int), s));
+    // Every workgroup gives its spill slot back on every exit path, so the flags are all clear after a solve that ran.  They are
+    // cleared at creation and again after a solve whose enqueue failed half way -- not per solve: with the chip held by another
+    // solve's fused workgroups even a memset node waits ~0.08 ms for a slot on this stream.
+    if (p->pool_dirty) {
+        HIPCHK(hipMemsetAsync(p->pool_flag.p, 0, (size_t)p->pool_n * 16 * sizeof(int), s));
+        p->pool_dirty = false;
+    }
     if (p->prof) HIPCHK(hipEventRecord(e4[0], s));
     if (p->d.mode == CFS_MODE_CFS) {     // unconstrained minimiser -H^{-1} ff (MFMA), constant over the outer loop
         GemvParams g;
