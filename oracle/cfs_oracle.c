@@ -12,7 +12,15 @@
  * Lib/CFS_FANUC.m:85, Lib/PSGCFS_FANUC.m:120).  The reference ships no tests,
  * golden vectors or fixtures for this path; the single known answer in the
  * repository is the doc-comment example of Lib/functions/distLinSeg.m:15-18,
- * which tests/test_oracle_geometry.py checks.  The QPs are strictly convex, so
+ * which tests/test_oracle_geometry.py checks.  Two stored OUTPUTS of the reference's
+ * MATLAB runs were found among its data files in round 3 and pin two functions of
+ * this file (tests/test_oracle_golden.py): figure/M16iBCapsules.mat:RoCap is CapPos's
+ * result for the M16iB (orc_arm_pos: 7.5e-16 m on 11 of 12 end points, the 12th a
+ * constant edited since), data/good_xori.mat + data/M16_ref_2.mat a stored
+ * (u -> x_) rollout (orc_rollout: all 240 doubles bit for bit).  Everything else --
+ * distLinSeg beyond its example, the near-zero surrogate, num_jac, get_con, the QP
+ * and the outer loops -- has no reference-held output: parity unpinned there.
+ * The QPs are strictly convex, so
  * the minimiser is unique; every solve here is certified by its KKT residuals
  * (orc_qp_kkt) and cross-checked in tests against an independent Lawson-Hanson
  * least-distance solve (scipy.optimize.nnls).

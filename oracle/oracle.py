@@ -10,8 +10,10 @@ It holds
     the drivers (main_FANUC.m:64-127, main_2L.m:69-121, RRTstar_CFS.m:124-187), plus the three
     deterministic demo problems those drivers define.
 
-PARITY STATUS: "parity unpinned" (see the header of cfs_oracle.c and DESIGN.md): the reference
-ships no tests or golden vectors and its QP solver (MathWorks quadprog) is closed source.
+PARITY STATUS: forward kinematics and the rollout are pinned by two outputs of the reference's own MATLAB runs found among
+its data files (figure/M16iBCapsules.mat:RoCap, data/good_xori.mat + data/M16_ref_2.mat; tests/test_oracle_golden.py); for
+everything else "parity unpinned" (see the header of cfs_oracle.c and DESIGN.md section 2): the reference ships no tests or
+golden vectors and its QP solver (MathWorks quadprog) is closed source.
 """
 from __future__ import annotations
 
