@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256) void cfs_dist_arm_kernel(DistArmParams P)
 // the register file), so each of its workgroups waits for a fused workgroup to retire -- 128 workgroups instead of 1 024 per
 // batch of 1 024: config 3 PSGCFS 1.467 -> 1.451 ms per solve, CFS 1.598 -> 1.586 (same-call A/B, two rounds; 16 grid-striding
 // workgroups instead: PSGCFS 1.489, CFS 1.578 -- the longer pre-pass costs the short solve more than the waiting saved).
+// __launch_bounds__(256, 4): 128 VGPRs (18 spilled) so that two of these workgroups fit the registers one retired fused workgroup
+// leaves: PSGCFS 1.4415 -> 1.4355 ms per solve.
 constexpr int ORDER_PB = 8;
-__global__ __launch_bounds__(256) void cfs_order_key_kernel(OrderParams P)
+__global__ __launch_bounds__(256, 4) void cfs_order_key_kernel(OrderParams P)
 {
     __shared__ __attribute__((aligned(16))) double s_rb[sizeof(DevRobot) / 8];
     __shared__ int s_cnt[ORDER_PB];
