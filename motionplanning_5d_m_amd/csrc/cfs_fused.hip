@@ -490,11 +490,22 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // flags are 64 bytes apart (one L2 line each: atomics on neighbours do not serialise); the probe starts at a hash of the
             // workgroup index so that workgroups starting together do not walk the same run of taken slots
             int sidx = (int)(((blockIdx.x * 0x9E3779B1u) >> 8) % (unsigned)P.pool_n);
-            while (atomicCAS(&P.pool_flag[sidx * 16], 0, 1) != 0) { sidx = sidx + 1 == P.pool_n ? 0 : sidx + 1; __builtin_amdgcn_s_sleep(2); }
+            // (bounded: there is a slot for every workgroup that can be resident, so a miss means a neighbour has not STARTED releasing
+            // yet; a pool whose flags were left set by a launch that never finished must not turn into a spin the GPU never leaves)
+            int probes = 0;
+            while (atomicCAS(&P.pool_flag[sidx * 16], 0, 1) != 0) {
+                sidx = sidx + 1 == P.pool_n ? 0 : sidx + 1;
+                __builtin_amdgcn_s_sleep(2);
+                if (++probes > (1 << 22)) { sidx = -1; break; }
+            }
             pubp[0] = sidx;
         }
         __syncthreads();
         pool_slot = pubp[0];
+        if (pool_slot < 0) {                               // reported (status NUMERIC), never waited out
+            if (tid == 0 && P.piece == 0) { P.status[b] = CFS_NUMERIC; P.iter_O[b] = 1; P.total_iter[b] = 0; }
+            return;
+        }
     }
     double *const s_pt = P.Pt + (size_t)pool_slot * P.pt_stride;
     double *s_Y = lds + L.y;                        // QY rows of HN doubles; linearisation scratch in between
