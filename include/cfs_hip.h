@@ -212,8 +212,9 @@ int cfs_get_cost(cfs_problem *p, int B, const double *u, const double *ff, const
  * When enabled, cfs_solve_batch_device brackets each kernel launch with hipEvents recorded on the
  * caller's stream (the reference has only tic/toc around the solver calls, main_FANUC.m:140-152).
  * cfs_profile_read synchronises on those events and returns, accumulated since the last read: the
- * milliseconds spent in the fused solve kernel and in the MFMA batched product, and the number of
- * solves. */
+ * milliseconds spent in the fused solve kernel (the event pair sits directly around its launch, after
+ * the launch-order pre-pass; for handles with mesh obstacles it spans the loop of per-iteration
+ * launches) and in the MFMA batched product, and the number of solves. */
 int cfs_profile_enable(cfs_problem *p, int on);
 int cfs_profile_read(cfs_problem *p, double *solve_kernel_ms, double *gemm_kernel_ms, int *solves);
 
