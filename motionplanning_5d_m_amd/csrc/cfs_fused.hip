@@ -945,9 +945,10 @@ __global__ __launch_bounds__(FT, CFS_WG_PER_CU) void cfs_solve_fused_kernel(Fuse
             // infeasible (Farkas, multipliers on the two rows and on box faces); so do a row of waypoint i and one of waypoint
             // i + 1 against one trapezoid step.  Config 3: 218 of the 327 infeasible linearisations, a quarter of all QP steps,
             // +20 % throughput.  Asked only once a QP has taken CERT_AT steps without finishing (ordinary QPs end in 1-5 steps
-            // and never pay for it).  H = I (PSGCFS): measured +-0 in throughput and +0.1 ms on the chain problems of a launch,
-            // so not compiled in there.
-            const bool cert_on = !IDENT && !(P.opt & 16) && nobs > 1;   // whole solves and the QP piece (cfs_qp) alike
+            // and never pay for it).  H = I (PSGCFS; no input bounds, so the boxes are the velocity ones alone): +-0 when it was first
+            // tried in round 2, +1.3 % on the round-3 kernel (1.435 -> 1.416 ms per solve, same-call A/B, results bit-identical but for
+            // the step counts; same registers and scratch), so it is compiled in for both Hessians.
+            const bool cert_on = !(P.opt & 16) && nobs > 1;   // whole solves and the QP piece (cfs_qp) alike
             auto certificate = [&]() -> bool {
                 int hit = 0;
                 for (int e = tid; e < H * nobs; e += FT) {

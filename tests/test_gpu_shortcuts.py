@@ -2,7 +2,7 @@
 (cfs_debug_set_options, include/cfs_hip.h) and compared with the default, on the config-3 batch (1024 problems, both
 solvers) and on 512 routes of config 4's shape.
 
-* step-free infeasibility certificate (CFS_FANUC): it only ever REPLACES the dual steps that would prove the same QP
+* step-free infeasibility certificate (both solvers since round 3): it only ever REPLACES the dual steps that would prove the same QP
   infeasible, so status, iteration counts, u and x_ must be the same BITS with and without it; and every linearisation it
   flags must be infeasible for the oracle's QP too (the reference ignores quadprog's exitflag, Lib/CFS_FANUC.m:85: what an
   infeasible QP "returns" there is undefined, so a wrong verdict here would be a silent change of behaviour).
@@ -40,14 +40,14 @@ def base(gpu, c3, c4):
     return {("c3", "CFS"): _solve(gpu, *c3, "CFS"), ("c3", "PSGCFS"): _solve(gpu, *c3, "PSGCFS"), ("c4", "CFS"): _solve(gpu, *c4, "CFS")}
 
 
-@pytest.mark.parametrize("tag", ["c3", "c4"])
-def test_certificate_on_off_same_bits(gpu, c3, c4, base, tag):
+@pytest.mark.parametrize("tag,mode", [("c3", "CFS"), ("c4", "CFS"), ("c3", "PSGCFS")])
+def test_certificate_on_off_same_bits(gpu, c3, c4, base, tag, mode):
     s, bt = c3 if tag == "c3" else c4
-    on, off = base[(tag, "CFS")], _solve(gpu, s, bt, "CFS", no_certificate=True)
+    on, off = base[(tag, mode)], _solve(gpu, s, bt, mode, no_certificate=True)
     for k in ("status", "iter_O", "u", "x_", "cost_all", "e_u_all"):
         np.testing.assert_array_equal(getattr(on, k), getattr(off, k), err_msg=k)
     saved = int(off.total_iter.sum()) - int(on.total_iter.sum())
-    print(f"[{tag}] certificate: {int((on.total_iter != off.total_iter).sum())} problems end earlier, {saved} of {int(off.total_iter.sum())} "
+    print(f"[{tag} {mode}] certificate: {int((on.total_iter != off.total_iter).sum())} problems end earlier, {saved} of {int(off.total_iter.sum())} "
           f"active-set steps saved; {int((on.status == 2).sum())} infeasible linearisations in all")
     assert (on.total_iter <= off.total_iter).all()
     if tag == "c3":
@@ -71,6 +71,41 @@ def test_other_rounding_same_answers(gpu, c3, c4, c3_oracle, c4_oracle, base, ta
     assert same[pinned].all(), np.nonzero(~same & pinned)[0]
     assert err[pinned].max() < 1e-5, (np.nonzero(pinned & (err >= 1e-5))[0], err[pinned].max())
     assert np.median(err[pinned]) < 1e-8, np.median(err[pinned])      # config-4 shape: cond(H) = 7e6, typical differences 1e-10 .. 1e-7
+
+
+def test_every_certificate_hit_is_infeasible_for_the_oracle_psgcfs(gpu, O, c3):
+    """The same for the projection QP of PSGCFS_FANUC (H = I, margins obs{j}.D, NO input bounds: Lib/PSGCFS_FANUC.m:117-120):
+    the first linearisation of every config-3 problem through cfs_qp, projecting the first PSG iterate u_ = -alpha (ff + 5 xi_1)."""
+    s, bt = c3
+    B, H, nn, nobs = bt.x_init.shape[0], s.H, s.H * 5, bt.nobs
+    margin = bt.margin_psg
+    u_ = -s.alpha * (bt.ff + 10.0 * bt.noise[:, 0] / 2.0)            # PSGCFS_FANUC.m:109 at u = 0, iter_O = 1
+    slv = gpu.CFSBatch(s, nobs, margin, mode="PSGCFS", max_batch=B)
+    dist, _, grad = slv.linearize(bt.x_init, bt.obs)
+    u_on, _, it_on, st_on = slv.qp(u_, np.zeros((B, nn)), bt.xR1, dist, grad, want_lambda=False)
+    slv.debug_options(no_certificate=True)
+    u_off, _, it_off, st_off = slv.qp(u_, np.zeros((B, nn)), bt.xR1, dist, grad, want_lambda=False)
+    slv.close()
+    np.testing.assert_array_equal(st_on, st_off)
+    np.testing.assert_array_equal(u_on[st_on == 0], u_off[st_on == 0])
+    hits = np.nonzero(it_on != it_off)[0]
+    assert (st_on[hits] == 2).all()
+    print(f"[c3 PSGCFS] certificate fired on {hits.size} of {int((st_on == 2).sum())} infeasible first projections ({B} problems)")
+    assert hits.size >= 20
+    from types import SimpleNamespace
+    import concurrent.futures as cf
+
+    def oracle_status(b):
+        s2 = SimpleNamespace(**vars(s))
+        s2.xR1, s2.robot = bt.xR1[b], O.robotproperty2("M200i")
+        A, rhs, od, _, og = O.get_con("M200i", s2, oracle_obs(bt, b, margin), bt.x_init[b], np.zeros(nn), mode="PSGCFS")
+        assert np.abs(od - dist[b]).max() < 1e-13 and np.abs(og - grad[b]).max() < 2e-9
+        return O.qp_solve(np.eye(nn), -u_[b], A, rhs)[3]
+
+    with cf.ThreadPoolExecutor(16) as ex:
+        sts = list(ex.map(oracle_status, hits.tolist()))
+    bad = [int(b) for b, st in zip(hits, sts) if st != 2]
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("tag", ["c3", "c4"])
